@@ -1,0 +1,132 @@
+/* polar_amd.h — C-ABI of the MI355X-native polar SC/SCL decoder (drop-in boundary).
+ *
+ * The reference (tavildar/Polar) has no FFI: its boundary is the public surface of
+ * `class PolarCode` (PolarC/PolarCode.h:19-34; MATLAB twin PolarM/PolarCode.m:59-93,
+ * 266-322, 781-850).  Every entry point below replaces one member of that surface
+ * (cited per function) with plain pointers and sizes, so that a MEX gateway, a cgo/ctypes
+ * stub or the C++ header-only mirror in polar_amd/cpp/PolarCode.hpp can bind it
+ * (INTEGRATION.md shows each binding).
+ *
+ * Conventions
+ *   - all functions return 0 on success, a negative POLAR_E_* code otherwise;
+ *     polar_last_error() returns a thread-local message. No exceptions cross the ABI.
+ *   - the caller owns every buffer; the library never retains a pointer past the call.
+ *   - "host" entry points take host pointers (H2D/D2H included); "_dev" entry points take
+ *     device pointers resident in HBM plus a hipStream_t passed as void*.
+ *   - LLR sign convention as the reference: llr = ln(p0/p1), positive => bit 0
+ *     (PolarCode.cpp:752). Bits are one uint8_t per bit (0/1), as the reference.
+ *   - a handle is bound to the HIP device that was current at creation; calls on one
+ *     handle must be serialised by the caller (the reference object is not re-entrant
+ *     either: PolarCode.h:56-68).
+ *   - the decoders run ONLY on the GPU: without a usable HIP device they fail with
+ *     POLAR_E_DEVICE. There is no CPU fallback in this library.
+ */
+#ifndef POLAR_AMD_H
+#define POLAR_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POLAR_OK 0
+#define POLAR_E_ARG (-1)      /* invalid argument (NULL, size, L out of range, ...) */
+#define POLAR_E_DEVICE (-2)   /* no HIP device / HIP runtime error */
+#define POLAR_E_NOMEM (-3)
+#define POLAR_E_UNSUPPORTED (-4)
+
+#define POLAR_MAX_N_LOG2 15   /* reference: uint16_t _block_length (PolarCode.h:40) */
+#define POLAR_MAX_LIST 64     /* reference loops forever for L > 127 (uint8_t, PolarCode.cpp:525) */
+#define POLAR_MAX_CRC 32
+
+typedef struct polar_code polar_code_t;
+
+const char *polar_last_error(void);
+/* library/ABI version: major*10000 + minor*100 + patch */
+int polar_version(void);
+
+/* ---- construction: PolarCode::PolarCode + create_bit_rev_order + initialize_frozen_bits
+ *      (PolarCode.h:19-28, PolarCode.cpp:17-58, 647-656).
+ * Bhattacharyya/BEC construction with design parameter `eps`; the info order is produced by
+ * the same libstdc++ std::sort call as the reference, and — exactly like the reference — the
+ * random-parity "CRC" matrix consumes crc*K draws of the process-global glibc rand() stream
+ * (PolarCode.cpp:51-56).  Use polar_create_explicit() to pass every table yourself. */
+int polar_create(int n, int K, double eps, int crc, polar_code_t **out);
+
+/* Explicit tables (e.g. a Monte-Carlo constructed code, PolarM/PolarCode.m:111-135):
+ * frozen[N] (1 = frozen), order[N] (= _channel_order_descending; only the first K+crc
+ * entries are used), crc_matrix[crc*K] row-major (may be NULL when crc == 0). */
+int polar_create_explicit(int n, int K, int crc, const uint8_t *frozen, const uint16_t *order,
+                          const uint8_t *crc_matrix, polar_code_t **out);
+void polar_destroy(polar_code_t *h);
+
+/* table getters (PolarCode.h:45-48) */
+int polar_get_params(const polar_code_t *h, int *n, int *N, int *K, int *crc);
+int polar_get_frozen(const polar_code_t *h, uint8_t *frozen /*[N]*/);
+int polar_get_order(const polar_code_t *h, uint16_t *order /*[N]*/);
+int polar_get_bitrev(const polar_code_t *h, uint16_t *bitrev /*[N]*/);
+int polar_get_crc_matrix(const polar_code_t *h, uint8_t *m /*[crc*K]*/);
+int polar_set_crc_matrix(polar_code_t *h, const uint8_t *m /*[crc*K]*/);
+
+/* ---- PolarCode::encode (PolarCode.cpp:60-91; PolarCode.m:266-276) ---- */
+int polar_encode(polar_code_t *h, const uint8_t *info /*[K]*/, uint8_t *coded /*[N]*/);
+int polar_encode_batch(polar_code_t *h, const uint8_t *info /*[B*K]*/, long B, uint8_t *coded /*[B*N]*/);
+int polar_encode_batch_dev(polar_code_t *h, const uint8_t *d_info, long B, uint8_t *d_coded, void *stream);
+
+/* ---- PolarCode::decode_scl_llr (PolarCode.cpp:130-148; PolarCode.m:312-322) ----
+ * 1 <= L <= POLAR_MAX_LIST.  out[K] = decoded information bits in the reference's order
+ * (Info[_channel_order_descending[beta]], PolarCode.cpp:172-174). */
+int polar_decode_scl_llr(polar_code_t *h, const double *llr /*[N]*/, int L, uint8_t *out /*[K]*/);
+/* batched, row-major, codeword-contiguous: llr[B*N] -> out[B*K] */
+int polar_decode_scl_llr_batch(polar_code_t *h, const double *llr, long B, int L, uint8_t *out);
+/* device-resident: d_llr/d_out live in HBM; asynchronous on `stream` (hipStream_t).
+ * d_pm (optional, may be NULL) receives the winning path metric per codeword. */
+int polar_decode_scl_llr_batch_dev(polar_code_t *h, const double *d_llr, long B, int L, uint8_t *d_out,
+                                   double *d_pm, void *stream);
+
+/* ---- PolarCode::decode_scl_p1 (PolarCode.cpp:110-128; PolarCode.m:299-310) ---- */
+int polar_decode_scl_p1(polar_code_t *h, const double *p1 /*[N]*/, const double *p0 /*[N]*/, int L, uint8_t *out /*[K]*/);
+int polar_decode_scl_p1_batch(polar_code_t *h, const double *p1, const double *p0, long B, int L, uint8_t *out);
+
+/* ---- PolarM decode_sc_p1 (PolarCode.m:290-295, 870-895): SC on p1 = P(bit = 1) ---- */
+int polar_decode_sc_p1(polar_code_t *h, const double *p1 /*[N]*/, uint8_t *out /*[K]*/);
+int polar_decode_sc_p1_batch(polar_code_t *h, const double *p1, long B, uint8_t *out);
+
+/* ---- synthetic BPSK/AWGN workload (include/polar_synth.h), generated on the device ----
+ * trials [trial0, trial0+B): info bits (block = trial/100), encode, BPSK, AWGN, LLR with
+ * the arithmetic of PolarCode.cpp:715,744-752; `s` = polar_snr_sqrt_linear(h, EbN0_dB).
+ * d_info (optional) receives the transmitted info bits [B*K]. */
+double polar_snr_sqrt_linear(const polar_code_t *h, double ebno_db);   /* PolarCode.cpp:744-745 */
+int polar_synth_llr_dev(polar_code_t *h, uint64_t seed, uint64_t trial0, long B, double s,
+                        double *d_llr, uint8_t *d_info, void *stream);
+/* compare decoded vs sent info bits on the device: *d_err_count += #codewords that differ */
+int polar_count_errors_dev(polar_code_t *h, const uint8_t *d_a, const uint8_t *d_b, long B,
+                           unsigned long long *d_err_count, void *stream);
+
+/* ---- PolarCode::get_bler_quick (PolarCode.cpp:658-785; PolarCode.m:781-850) ----
+ * Batched Monte-Carlo on the synthetic workload. Semantics of the reference kept per trial
+ * (one noise vector shared by every (L, Eb/N0); ascending Eb/N0 with "decoded at a lower
+ * Eb/N0 => counted, not simulated", :728-742); the early stop `num_err > max_err` (:725)
+ * is evaluated between batches of `batch` trials (batch = 1 reproduces the reference's
+ * per-run granularity).  Reference defaults: max_runs = 1000, max_err = 100 (:661-662).
+ * Sharding: this rank simulates trials t with t % world == rank (counter-based RNG makes
+ * the union independent of `world`); err/run accumulators are returned so the caller can
+ * all-reduce them (RCCL) between batches: see polar_mc_* below for the step-wise form. */
+int polar_get_bler_quick(polar_code_t *h, const double *ebno, int n_e, const uint8_t *L, int n_L,
+                         long max_runs, long max_err, uint64_t seed, long batch,
+                         double *bler_out /*[n_L*n_e]*/);
+
+/* step-wise Monte-Carlo for multi-GPU drivers: simulate trials {t0 + i*stride : i < T} for
+ * every enabled (L, Eb/N0) point and ADD to err/run (host uint64 [n_L*n_e]). */
+int polar_mc_batch(polar_code_t *h, uint64_t seed, uint64_t t0, long T, long stride,
+                   const double *ebno, int n_e, const uint8_t *L, int n_L,
+                   const uint8_t *enabled /*[n_L*n_e]*/, uint64_t *err, uint64_t *run);
+
+/* tuning knobs (0 = default): waves resident per CU and LDS-resident layer exponent */
+int polar_set_tuning(polar_code_t *h, int waves_per_cu, int lds_log);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POLAR_AMD_H */

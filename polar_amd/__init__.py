@@ -1,0 +1,249 @@
+"""polar_amd — MI355X-native polar SC/SCL decoder: Python host mirror of the reference's
+``PolarCode`` class surface (PolarC/PolarCode.h:19-34, PolarM/PolarCode.m:59-93,266-322,781-850)
+over the C-ABI of include/polar_amd.h.
+
+This module is plumbing only: every compute call goes through ``libpolar_amd.so`` (hand-written
+HIP kernels for gfx950). There is NO CPU fallback: if the shared library is missing, or no HIP
+device is usable, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+try:  # must precede loading libpolar_amd.so so both share ONE HIP runtime (see build.py)
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is plumbing; the library also works stand-alone
+    torch = None
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpolar_amd.so")
+
+_dp = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+_u16p = C.POINTER(C.c_uint16)
+_u64p = C.POINTER(C.c_uint64)
+
+
+class PolarError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libpolar_amd.so (built by polar_amd.build.build()); raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PolarError(
+                f"{LIB_PATH} not found: build it with `python -m polar_amd.build` "
+                "(the HIP extension is mandatory; there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.polar_last_error.restype = C.c_char_p
+        L.polar_snr_sqrt_linear.restype = C.c_double
+        L.polar_snr_sqrt_linear.argtypes = [C.c_void_p, C.c_double]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise PolarError(f"polar_amd error {rc}: {lib().polar_last_error().decode()}")
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        if torch is not None and torch.cuda.is_available():
+            return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return C.c_void_p(0)
+    if hasattr(stream, "cuda_stream"):
+        return C.c_void_p(stream.cuda_stream)
+    return C.c_void_p(int(stream))
+
+
+class PolarCode:
+    """Drop-in for the reference ``PolarCode``.
+
+    ``PolarCode(num_layers, info_length, epsilon, crc_size)`` follows PolarC (PolarCode.h:19);
+    ``PolarCode.from_block_length(block_length, info_length, design_epsilon, crc_size=0)`` follows
+    PolarM's argument order (PolarCode.m:59). ``PolarCode.from_tables`` takes explicit tables.
+    """
+
+    def __init__(self, num_layers, info_length, epsilon, crc_size=0, _handle=None):
+        L = lib()
+        self._h = C.c_void_p()
+        if _handle is not None:
+            self._h = _handle
+        else:
+            _check(L.polar_create(C.c_int(num_layers), C.c_int(info_length), C.c_double(epsilon),
+                                  C.c_int(crc_size), C.byref(self._h)))
+        n, N, K, crc = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _check(L.polar_get_params(self._h, C.byref(n), C.byref(N), C.byref(K), C.byref(crc)))
+        self.n, self.block_length, self.info_length, self.crc_size = n.value, N.value, K.value, crc.value
+        self.N, self.K = self.block_length, self.info_length
+
+    @classmethod
+    def from_block_length(cls, block_length, info_length, design_epsilon, crc_size=0):
+        n = int(round(np.log2(block_length)))
+        if (1 << n) != block_length:
+            raise PolarError("block_length must be a power of two")
+        return cls(n, info_length, design_epsilon, crc_size)
+
+    @classmethod
+    def from_tables(cls, num_layers, info_length, crc_size, frozen, order, crc_matrix=None):
+        frozen = np.ascontiguousarray(frozen, np.uint8)
+        order = np.ascontiguousarray(order, np.uint16)
+        N = 1 << num_layers
+        if frozen.shape != (N,) or order.shape != (N,):
+            raise PolarError("frozen/order must have N entries")
+        cm = None
+        if crc_size:
+            cm = np.ascontiguousarray(crc_matrix, np.uint8)
+            if cm.shape != (crc_size, info_length):
+                raise PolarError("crc_matrix must be crc x K")
+        h = C.c_void_p()
+        _check(lib().polar_create_explicit(C.c_int(num_layers), C.c_int(info_length), C.c_int(crc_size),
+                                           _p(frozen, _u8p), _p(order, _u16p),
+                                           _p(cm, _u8p) if cm is not None else None, C.byref(h)))
+        return cls(num_layers, info_length, float("nan"), crc_size, _handle=h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().polar_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- tables ------------------------------------------------------------------------
+    @property
+    def frozen_bits(self):
+        a = np.zeros(self.N, np.uint8)
+        _check(lib().polar_get_frozen(self._h, _p(a, _u8p)))
+        return a
+
+    @property
+    def channel_order_descending(self):
+        a = np.zeros(self.N, np.uint16)
+        _check(lib().polar_get_order(self._h, _p(a, _u16p)))
+        return a
+
+    @property
+    def bit_rev_order(self):
+        a = np.zeros(self.N, np.uint16)
+        _check(lib().polar_get_bitrev(self._h, _p(a, _u16p)))
+        return a
+
+    @property
+    def crc_matrix(self):
+        a = np.zeros((self.crc_size, self.K), np.uint8)
+        if self.crc_size:
+            _check(lib().polar_get_crc_matrix(self._h, _p(a, _u8p)))
+        return a
+
+    @crc_matrix.setter
+    def crc_matrix(self, m):
+        m = np.ascontiguousarray(m, np.uint8)
+        if m.shape != (self.crc_size, self.K):
+            raise PolarError("crc_matrix must be crc x K")
+        if self.crc_size:
+            _check(lib().polar_set_crc_matrix(self._h, _p(m, _u8p)))
+
+    def set_tuning(self, waves_per_cu=0, lds_log=0):
+        _check(lib().polar_set_tuning(self._h, C.c_int(waves_per_cu), C.c_int(lds_log)))
+
+    def snr_sqrt_linear(self, ebno_db):
+        return lib().polar_snr_sqrt_linear(self._h, C.c_double(ebno_db))
+
+    # ---- encode (PolarCode.cpp:60-91) ---------------------------------------------------
+    def encode(self, info_bits):
+        info = np.ascontiguousarray(info_bits, np.uint8)
+        single = info.ndim == 1
+        info2 = info.reshape(-1, self.K)
+        out = np.zeros((info2.shape[0], self.N), np.uint8)
+        _check(lib().polar_encode_batch(self._h, _p(info2, _u8p), C.c_long(info2.shape[0]), _p(out, _u8p)))
+        return out[0] if single else out
+
+    # ---- decoders -----------------------------------------------------------------------
+    def decode_scl_llr(self, llr, list_size):
+        """PolarCode::decode_scl_llr (PolarCode.cpp:130-148). `llr` is [N] or [B, N] float64."""
+        a = np.ascontiguousarray(llr, np.float64)
+        single = a.ndim == 1
+        a2 = a.reshape(-1, self.N)
+        out = np.zeros((a2.shape[0], self.K), np.uint8)
+        _check(lib().polar_decode_scl_llr_batch(self._h, _p(a2, _dp), C.c_long(a2.shape[0]), C.c_int(list_size),
+                                                _p(out, _u8p)))
+        return out[0] if single else out
+
+    def decode_scl_p1(self, p1, p0, list_size):
+        """PolarCode::decode_scl_p1 (PolarCode.cpp:110-128)."""
+        a = np.ascontiguousarray(p1, np.float64)
+        b = np.ascontiguousarray(p0, np.float64)
+        single = a.ndim == 1
+        a2, b2 = a.reshape(-1, self.N), b.reshape(-1, self.N)
+        out = np.zeros((a2.shape[0], self.K), np.uint8)
+        _check(lib().polar_decode_scl_p1_batch(self._h, _p(a2, _dp), _p(b2, _dp), C.c_long(a2.shape[0]),
+                                               C.c_int(list_size), _p(out, _u8p)))
+        return out[0] if single else out
+
+    def decode_sc_p1(self, p1):
+        """PolarM decode_sc_p1 (PolarCode.m:290-295)."""
+        a = np.ascontiguousarray(p1, np.float64)
+        single = a.ndim == 1
+        a2 = a.reshape(-1, self.N)
+        out = np.zeros((a2.shape[0], self.K), np.uint8)
+        _check(lib().polar_decode_sc_p1_batch(self._h, _p(a2, _dp), C.c_long(a2.shape[0]), _p(out, _u8p)))
+        return out[0] if single else out
+
+    # names used by BASELINE.json's north_star
+    decode_SCL_LLR = decode_scl_llr
+    decode_SCL_P1 = decode_scl_p1
+    decode_SC_P1 = decode_sc_p1
+
+    # ---- device-resident entry points (torch tensors are only memory + stream plumbing) ---
+    def decode_scl_llr_dev(self, llr_ptr, B, list_size, out_ptr, pm_ptr=0, stream=None):
+        _check(lib().polar_decode_scl_llr_batch_dev(self._h, C.c_void_p(llr_ptr), C.c_long(B), C.c_int(list_size),
+                                                    C.c_void_p(out_ptr), C.c_void_p(pm_ptr), _stream_ptr(stream)))
+
+    def synth_llr_dev(self, seed, trial0, B, s, llr_ptr, info_ptr=0, stream=None):
+        _check(lib().polar_synth_llr_dev(self._h, C.c_uint64(seed), C.c_uint64(trial0), C.c_long(B), C.c_double(s),
+                                         C.c_void_p(llr_ptr), C.c_void_p(info_ptr), _stream_ptr(stream)))
+
+    def count_errors_dev(self, a_ptr, b_ptr, B, counter_ptr, stream=None):
+        _check(lib().polar_count_errors_dev(self._h, C.c_void_p(a_ptr), C.c_void_p(b_ptr), C.c_long(B),
+                                            C.c_void_p(counter_ptr), _stream_ptr(stream)))
+
+    def encode_dev(self, info_ptr, B, coded_ptr, stream=None):
+        _check(lib().polar_encode_batch_dev(self._h, C.c_void_p(info_ptr), C.c_long(B), C.c_void_p(coded_ptr),
+                                            _stream_ptr(stream)))
+
+    # ---- Monte-Carlo (PolarCode.cpp:658-785) ---------------------------------------------
+    def mc_batch(self, seed, t0, T, stride, ebno_vec, list_size_vec, enabled, err, run):
+        ebno = np.ascontiguousarray(ebno_vec, np.float64)
+        Ls = np.ascontiguousarray(list_size_vec, np.uint8)
+        enabled = np.ascontiguousarray(enabled, np.uint8)
+        assert err.dtype == np.uint64 and run.dtype == np.uint64
+        _check(lib().polar_mc_batch(self._h, C.c_uint64(seed), C.c_uint64(t0), C.c_long(T), C.c_long(stride),
+                                    _p(ebno, _dp), C.c_int(len(ebno)), _p(Ls, _u8p), C.c_int(len(Ls)),
+                                    _p(enabled, _u8p), _p(err, _u64p), _p(run, _u64p)))
+
+    def get_bler_quick(self, ebno_vec, list_size_vec, max_runs=1000, max_err=100, seed=1, batch=None):
+        """PolarCode::get_bler_quick: returns bler[len(list_size_vec)][len(ebno_vec)]."""
+        ebno = np.ascontiguousarray(ebno_vec, np.float64)
+        Ls = np.ascontiguousarray(list_size_vec, np.uint8)
+        out = np.zeros((len(Ls), len(ebno)), np.float64)
+        if batch is None:
+            batch = max_runs
+        _check(lib().polar_get_bler_quick(self._h, _p(ebno, _dp), C.c_int(len(ebno)), _p(Ls, _u8p), C.c_int(len(Ls)),
+                                          C.c_long(max_runs), C.c_long(max_err), C.c_uint64(seed), C.c_long(batch),
+                                          _p(out, _dp)))
+        return out

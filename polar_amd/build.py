@@ -1,0 +1,77 @@
+"""Build the in-tree HIP library polar_amd/libpolar_amd.so for gfx950.
+
+hipcc cross-compiles without a GPU. The shared object is linked against the libamdhip64 that
+PyTorch-ROCm bundles (DT_NEEDED "libamdhip64.so"), so that when it is loaded into a process
+that already imported torch both share ONE HIP runtime (device pointers and streams handed
+over from torch are then valid); stand-alone (C++/MATLAB hosts) the same name resolves to
+/opt/rocm/lib through the rpath.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+INC = os.path.join(ROOT, "include")
+LIB = os.path.join(HERE, "libpolar_amd.so")
+BUILD = os.path.join(HERE, "_build")
+SOURCES = ["polar_kernels.hip", "polar_channel.hip", "polar_host.cpp"]
+ARCH = "gfx950"
+
+
+def _hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _torch_lib():
+    try:
+        import torch  # noqa: F401  (plumbing only: locate the bundled HIP runtime)
+        d = os.path.join(os.path.dirname(torch.__file__), "lib")
+        if os.path.exists(os.path.join(d, "libamdhip64.so")):
+            return d
+    except Exception:
+        pass
+    return None
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(BUILD, exist_ok=True)
+    headers = [os.path.join(INC, f) for f in os.listdir(INC)] + \
+              [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    objs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(BUILD, s + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [src] + headers + [os.path.abspath(__file__)]):
+            cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                   "-Wall", "-Wno-unused-function", "-x", "hip", "-I", INC, "-I", CSRC, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+    if force or _newer(LIB, objs):
+        tl = _torch_lib()
+        cmd = [_hipcc(), "-shared", "-fPIC", "-o", LIB] + objs
+        if tl:
+            # hipcc would add -L/opt/rocm/lib -lamdhip64 itself; link by hand instead so the
+            # DT_NEEDED entry is the un-versioned name torch's copy is loaded under
+            clang = "/opt/rocm/lib/llvm/bin/clang++"
+            cmd = [clang, "-shared", "-fPIC", "-o", LIB] + objs + \
+                  ["-L" + tl, "-lamdhip64", "-Wl,-rpath," + tl, "-Wl,-rpath,/opt/rocm/lib", "-lstdc++", "-lm"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,483 @@
+// polar_host.cpp — C-ABI of include/polar_amd.h: handle, code tables, device plumbing.
+//
+// Host-side counterpart of the reference's PolarCode object (PolarC/PolarCode.h:17-90):
+// the constructor work (bit-reversal table, Bhattacharyya construction, random-parity matrix)
+// runs once on the host and is uploaded as small device tables; everything per-codeword
+// (encode, channel, SC/SCL decode, error counting) runs in the HIP kernels. There is no CPU
+// decode path here: without a HIP device every compute entry point fails with POLAR_E_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "polar_amd.h"
+#include "polar_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(POLAR_E_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;   // elements
+    int ensure(size_t n) {
+        if (n <= cap) return POLAR_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
+        if (e != hipSuccess) return fail(POLAR_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
+        cap = n;
+        return POLAR_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct polar_code {
+    int n = 0, N = 0, K = 0, crc = 0;
+    double eps = 0.0;
+    std::vector<uint8_t> frozen;     // [N]
+    std::vector<uint16_t> order;     // [N]
+    std::vector<uint16_t> bitrev;    // [N]
+    std::vector<uint8_t> crcm;       // [crc*K]
+    // derived
+    int W = 0;
+    std::vector<uint16_t> info_rank; // [K+crc]
+    std::vector<uint32_t> crc_mask;  // [crc*W]
+    // device
+    bool dev_ready = false;
+    int device = -1, num_cu = 0;
+    DevBuf<uint8_t> d_frozen, d_crcm;
+    DevBuf<uint16_t> d_order, d_info_rank;
+    DevBuf<uint32_t> d_crc_mask;
+    DevBuf<double> d_llr_scr;
+    DevBuf<uint32_t> d_c_scr, d_hist_scr;
+    // staging for the host-pointer entry points
+    DevBuf<double> d_in;
+    DevBuf<uint8_t> d_out, d_bytes_a, d_bytes_b;
+    DevBuf<unsigned long long> d_counter;
+    DevBuf<uint64_t> d_sel;
+    // tuning
+    int waves_per_cu = 0, lds_log = 0;
+};
+
+namespace {
+
+void make_bitrev(polar_code *h) {   // create_bit_rev_order, PolarCode.cpp:647-656
+    h->bitrev.resize(h->N);
+    for (int i = 0; i < h->N; ++i) {
+        unsigned r = 0;
+        for (int b = 0; b < h->n; ++b) r |= ((unsigned(i) >> b) & 1u) << (h->n - 1 - b);
+        h->bitrev[i] = (uint16_t)r;
+    }
+}
+
+int derive_tables(polar_code *h) {
+    const int N = h->N, K = h->K, crc = h->crc, E = K + crc;
+    // the first K+crc entries of `order` must be exactly the unfrozen positions
+    std::vector<int> rank(N, -1);
+    int t = 0;
+    for (int i = 0; i < N; ++i) if (!h->frozen[i]) rank[i] = t++;
+    if (t != E) return fail(POLAR_E_ARG, "frozen mask has %d unfrozen positions, expected K+crc = %d", t, E);
+    std::vector<uint8_t> seen(N, 0);
+    h->info_rank.assign(E, 0);
+    for (int b = 0; b < E; ++b) {
+        int pos = h->order[b];
+        if (pos >= N || rank[pos] < 0 || seen[pos])
+            return fail(POLAR_E_ARG, "order[%d] = %d is frozen, duplicate or out of range", b, pos);
+        seen[pos] = 1;
+        h->info_rank[b] = (uint16_t)rank[pos];
+    }
+    h->W = (E + 31) / 32;
+    if (h->W == 0) h->W = 1;
+    // CRC row i as a parity mask over unfrozen ranks, check bit included: crc_check passes iff
+    // parity(history & mask_i) == 0 for every row (PolarCode.cpp:93-108)
+    h->crc_mask.assign((size_t)crc * h->W, 0u);
+    for (int i = 0; i < crc; ++i) {
+        uint32_t *m = &h->crc_mask[(size_t)i * h->W];
+        for (int j = 0; j < K; ++j)
+            if (h->crcm[(size_t)i * K + j] & 1) m[h->info_rank[j] >> 5] ^= 1u << (h->info_rank[j] & 31);
+        int r = h->info_rank[K + i];
+        m[r >> 5] ^= 1u << (r & 31);
+    }
+    return POLAR_OK;
+}
+
+template <typename T>
+int upload(DevBuf<T> &d, const std::vector<T> &v) {
+    size_t n = v.size() ? v.size() : 1;
+    int rc = d.ensure(n);
+    if (rc) return rc;
+    if (v.size()) HIP_TRY(hipMemcpy(d.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return POLAR_OK;
+}
+
+int ensure_device(polar_code *h) {
+    if (h->dev_ready) {
+        HIP_TRY(hipSetDevice(h->device));
+        return POLAR_OK;
+    }
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt <= 0)
+        return fail(POLAR_E_DEVICE, "no HIP device available (%s); this library has no CPU decode path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    HIP_TRY(hipGetDevice(&h->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+    h->num_cu = prop.multiProcessorCount;
+    int rc;
+    if ((rc = upload(h->d_frozen, h->frozen))) return rc;
+    if ((rc = upload(h->d_order, h->order))) return rc;
+    if ((rc = upload(h->d_info_rank, h->info_rank))) return rc;
+    if ((rc = upload(h->d_crc_mask, h->crc_mask))) return rc;
+    if ((rc = upload(h->d_crcm, h->crcm))) return rc;
+    h->dev_ready = true;
+    return POLAR_OK;
+}
+
+int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+}  // namespace
+
+extern "C" {
+
+const char *polar_last_error(void) { return g_err.c_str(); }
+int polar_version(void) { return 100; }
+
+int polar_create(int n, int K, double eps, int crc, polar_code_t **out) {
+    if (!out) return fail(POLAR_E_ARG, "out is NULL");
+    if (n < 1 || n > POLAR_MAX_N_LOG2) return fail(POLAR_E_ARG, "n = %d out of range [1, %d]", n, POLAR_MAX_N_LOG2);
+    const int N = 1 << n;
+    if (K < 1 || crc < 0 || crc > POLAR_MAX_CRC || K + crc > N)
+        return fail(POLAR_E_ARG, "need 1 <= K, 0 <= crc <= %d, K + crc <= N (K=%d crc=%d N=%d)", POLAR_MAX_CRC, K, crc, N);
+    polar_code *h = new polar_code;
+    h->n = n; h->N = N; h->K = K; h->crc = crc; h->eps = eps;
+    make_bitrev(h);
+    // initialize_frozen_bits (PolarCode.cpp:17-58): BEC/Bhattacharyya recursion ...
+    std::vector<double> z(N, eps);
+    for (int it = 0; it < n; ++it) {
+        const int inc = 1 << it;
+        for (int j = 0; j < inc; ++j)
+            for (int i = 0; i < N; i += 2 * inc) {
+                double c1 = z[i + j], c2 = z[i + j + inc];
+                z[i + j] = c1 + c2 - c1 * c2;
+                z[i + j + inc] = c1 * c2;
+            }
+    }
+    // ... then the SAME library call as the reference (std::sort on uint16_t indices with the
+    // comparator of PolarCode.cpp:40), so that ties (e.g. channels whose parameter underflowed
+    // to 0.0) land in the reference's order under the same libstdc++.
+    h->order.resize(N);
+    std::iota(h->order.begin(), h->order.end(), (uint16_t)0);
+    const std::vector<uint16_t> &br = h->bitrev;
+    std::sort(h->order.begin(), h->order.end(), [&](int i1, int i2) { return z[br[i1]] < z[br[i2]]; });
+    h->frozen.assign(N, 1);
+    for (int i = 0; i < K + crc; ++i) h->frozen[h->order[i]] = 0;
+    // random-parity "CRC": crc*K draws of the process-global rand(), as PolarCode.cpp:51-56
+    h->crcm.resize((size_t)crc * K);
+    for (int b = 0; b < crc; ++b)
+        for (int j = 0; j < K; ++j) h->crcm[(size_t)b * K + j] = (uint8_t)(rand() % 2);
+    int rc = derive_tables(h);
+    if (rc) { delete h; return rc; }
+    *out = h;
+    return POLAR_OK;
+}
+
+int polar_create_explicit(int n, int K, int crc, const uint8_t *frozen, const uint16_t *order,
+                          const uint8_t *crc_matrix, polar_code_t **out) {
+    if (!out || !frozen || !order) return fail(POLAR_E_ARG, "NULL argument");
+    if (n < 1 || n > POLAR_MAX_N_LOG2) return fail(POLAR_E_ARG, "n = %d out of range", n);
+    const int N = 1 << n;
+    if (K < 1 || crc < 0 || crc > POLAR_MAX_CRC || K + crc > N) return fail(POLAR_E_ARG, "bad K/crc");
+    if (crc > 0 && !crc_matrix) return fail(POLAR_E_ARG, "crc_matrix is NULL with crc = %d", crc);
+    polar_code *h = new polar_code;
+    h->n = n; h->N = N; h->K = K; h->crc = crc; h->eps = NAN;
+    make_bitrev(h);
+    h->frozen.assign(frozen, frozen + N);
+    h->order.assign(order, order + N);
+    h->crcm.assign((size_t)crc * K, 0);
+    if (crc) memcpy(h->crcm.data(), crc_matrix, (size_t)crc * K);
+    int rc = derive_tables(h);
+    if (rc) { delete h; return rc; }
+    *out = h;
+    return POLAR_OK;
+}
+
+void polar_destroy(polar_code_t *h) {
+    if (!h) return;
+    if (h->dev_ready) (void)hipSetDevice(h->device);
+    h->d_frozen.release(); h->d_crcm.release(); h->d_order.release(); h->d_info_rank.release();
+    h->d_crc_mask.release(); h->d_llr_scr.release(); h->d_c_scr.release(); h->d_hist_scr.release();
+    h->d_in.release(); h->d_out.release(); h->d_bytes_a.release(); h->d_bytes_b.release();
+    h->d_counter.release(); h->d_sel.release();
+    delete h;
+}
+
+int polar_get_params(const polar_code_t *h, int *n, int *N, int *K, int *crc) {
+    if (!h) return fail(POLAR_E_ARG, "NULL handle");
+    if (n) *n = h->n;
+    if (N) *N = h->N;
+    if (K) *K = h->K;
+    if (crc) *crc = h->crc;
+    return POLAR_OK;
+}
+int polar_get_frozen(const polar_code_t *h, uint8_t *o) {
+    if (!h || !o) return fail(POLAR_E_ARG, "NULL argument");
+    memcpy(o, h->frozen.data(), h->N); return POLAR_OK;
+}
+int polar_get_order(const polar_code_t *h, uint16_t *o) {
+    if (!h || !o) return fail(POLAR_E_ARG, "NULL argument");
+    memcpy(o, h->order.data(), 2 * (size_t)h->N); return POLAR_OK;
+}
+int polar_get_bitrev(const polar_code_t *h, uint16_t *o) {
+    if (!h || !o) return fail(POLAR_E_ARG, "NULL argument");
+    memcpy(o, h->bitrev.data(), 2 * (size_t)h->N); return POLAR_OK;
+}
+int polar_get_crc_matrix(const polar_code_t *h, uint8_t *m) {
+    if (!h || (!m && h->crc)) return fail(POLAR_E_ARG, "NULL argument");
+    if (h->crc) memcpy(m, h->crcm.data(), (size_t)h->crc * h->K);
+    return POLAR_OK;
+}
+int polar_set_crc_matrix(polar_code_t *h, const uint8_t *m) {
+    if (!h || (!m && h->crc)) return fail(POLAR_E_ARG, "NULL argument");
+    if (h->crc) memcpy(h->crcm.data(), m, (size_t)h->crc * h->K);
+    int rc = derive_tables(h);
+    if (rc) return rc;
+    if (h->dev_ready) {
+        if ((rc = upload(h->d_crc_mask, h->crc_mask))) return rc;
+        if ((rc = upload(h->d_crcm, h->crcm))) return rc;
+    }
+    return POLAR_OK;
+}
+
+int polar_set_tuning(polar_code_t *h, int waves_per_cu, int lds_log) {
+    if (!h) return fail(POLAR_E_ARG, "NULL handle");
+    if (waves_per_cu < 0 || waves_per_cu > 32) return fail(POLAR_E_ARG, "waves_per_cu out of range");
+    if (lds_log != 0 && (lds_log < 3 || lds_log > 5)) return fail(POLAR_E_ARG, "lds_log must be 0 or 3..5");
+    h->waves_per_cu = waves_per_cu;
+    h->lds_log = lds_log;
+    return POLAR_OK;
+}
+
+double polar_snr_sqrt_linear(const polar_code_t *h, double ebno_db) {   // PolarCode.cpp:744-745
+    return std::pow(10.0f, ebno_db / 20) * std::sqrt(((double)h->K) / ((double)h->N));
+}
+
+// ------------------------------------------------------------------------------------------
+int polar_decode_scl_llr_batch_dev(polar_code_t *h, const double *d_llr, long B, int L, uint8_t *d_out,
+                                   double *d_pm, void *stream) {
+    if (!h || !d_llr || !d_out) return fail(POLAR_E_ARG, "NULL argument");
+    if (L < 1 || L > POLAR_MAX_LIST) return fail(POLAR_E_ARG, "list size %d out of range [1, %d]", L, POLAR_MAX_LIST);
+    if (B < 0) return fail(POLAR_E_ARG, "negative batch");
+    if (B == 0) return POLAR_OK;
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    const int gs = pow2ceil(L);
+    const int G = 64 / gs;
+    int lds_log = h->lds_log ? h->lds_log : 4;
+    const size_t lds = polar_decode_lds_bytes(lds_log);
+    int wpc = h->waves_per_cu ? h->waves_per_cu : 8;
+    const int max_by_lds = (int)((160 * 1024) / lds);
+    if (wpc > max_by_lds) wpc = max_by_lds;
+    long groups = (B + G - 1) / G;
+    long maxgrid = (long)h->num_cu * wpc;
+    int grid = (int)std::min(groups, maxgrid);
+    const int SL = 1 << lds_log;
+    const size_t big = (h->N > 2 * SL) ? (size_t)(h->N - 2 * SL) : 0;
+    const size_t cwords = (h->N >= 128) ? (size_t)(h->N / 32 - 2) : 0;
+    if ((rc = h->d_llr_scr.ensure((size_t)grid * big * 64 + 64))) return rc;
+    if ((rc = h->d_c_scr.ensure((size_t)grid * 2 * cwords * 64 + 64))) return rc;
+    if ((rc = h->d_hist_scr.ensure((size_t)grid * h->W * 64 + 64))) return rc;
+    PolarDecodeParams p;
+    p.n = h->n; p.N = h->N; p.K = h->K; p.crc = h->crc; p.L = L; p.W = h->W; p.B = B;
+    p.llr = d_llr; p.out = d_out; p.pm_out = d_pm;
+    p.frozen = h->d_frozen.p; p.info_rank = h->d_info_rank.p; p.crc_mask = h->d_crc_mask.p;
+    p.llr_scr = h->d_llr_scr.p; p.c_scr = h->d_c_scr.p; p.hist_scr = h->d_hist_scr.p;
+    HIP_TRY(polar_launch_decode_llr(p, gs, lds_log, grid, (hipStream_t)stream));
+    return POLAR_OK;
+}
+
+int polar_decode_scl_llr_batch(polar_code_t *h, const double *llr, long B, int L, uint8_t *out) {
+    if (!h || !llr || !out) return fail(POLAR_E_ARG, "NULL argument");
+    if (B < 0) return fail(POLAR_E_ARG, "negative batch");
+    if (B == 0) return POLAR_OK;
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    if ((rc = h->d_in.ensure((size_t)B * h->N))) return rc;
+    if ((rc = h->d_out.ensure((size_t)B * h->K))) return rc;
+    HIP_TRY(hipMemcpy(h->d_in.p, llr, (size_t)B * h->N * sizeof(double), hipMemcpyHostToDevice));
+    rc = polar_decode_scl_llr_batch_dev(h, h->d_in.p, B, L, h->d_out.p, nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, h->d_out.p, (size_t)B * h->K, hipMemcpyDeviceToHost));
+    return POLAR_OK;
+}
+
+int polar_decode_scl_llr(polar_code_t *h, const double *llr, int L, uint8_t *out) {
+    return polar_decode_scl_llr_batch(h, llr, 1, L, out);
+}
+
+int polar_decode_scl_p1(polar_code_t *, const double *, const double *, int, uint8_t *) {
+    return fail(POLAR_E_UNSUPPORTED, "decode_scl_p1: probability-domain SCL is not implemented yet (SURVEY 8f N3)");
+}
+int polar_decode_scl_p1_batch(polar_code_t *, const double *, const double *, long, int, uint8_t *) {
+    return fail(POLAR_E_UNSUPPORTED, "decode_scl_p1: probability-domain SCL is not implemented yet (SURVEY 8f N3)");
+}
+int polar_decode_sc_p1(polar_code_t *, const double *, uint8_t *) {
+    return fail(POLAR_E_UNSUPPORTED, "decode_sc_p1 is not implemented yet");
+}
+int polar_decode_sc_p1_batch(polar_code_t *, const double *, long, uint8_t *) {
+    return fail(POLAR_E_UNSUPPORTED, "decode_sc_p1 is not implemented yet");
+}
+
+// ------------------------------------------------------------------------------------------
+static void fill_enc(const polar_code *h, PolarEncodeParams &p) {
+    memset(&p, 0, sizeof p);
+    p.n = h->n; p.N = h->N; p.K = h->K; p.crc = h->crc;
+    p.order = h->d_order.p; p.crcm = h->d_crcm.p;
+    p.stride = 1;
+}
+
+int polar_encode_batch_dev(polar_code_t *h, const uint8_t *d_info, long B, uint8_t *d_coded, void *stream) {
+    if (!h || !d_info || !d_coded) return fail(POLAR_E_ARG, "NULL argument");
+    if (B <= 0) return B == 0 ? POLAR_OK : fail(POLAR_E_ARG, "negative batch");
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    PolarEncodeParams p;
+    fill_enc(h, p);
+    p.B = B; p.info = d_info; p.coded = d_coded;
+    HIP_TRY(polar_launch_encode(p, (hipStream_t)stream));
+    return POLAR_OK;
+}
+
+int polar_encode_batch(polar_code_t *h, const uint8_t *info, long B, uint8_t *coded) {
+    if (!h || !info || !coded) return fail(POLAR_E_ARG, "NULL argument");
+    if (B <= 0) return B == 0 ? POLAR_OK : fail(POLAR_E_ARG, "negative batch");
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    if ((rc = h->d_bytes_a.ensure((size_t)B * h->K))) return rc;
+    if ((rc = h->d_bytes_b.ensure((size_t)B * h->N))) return rc;
+    HIP_TRY(hipMemcpy(h->d_bytes_a.p, info, (size_t)B * h->K, hipMemcpyHostToDevice));
+    if ((rc = polar_encode_batch_dev(h, h->d_bytes_a.p, B, h->d_bytes_b.p, nullptr))) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(coded, h->d_bytes_b.p, (size_t)B * h->N, hipMemcpyDeviceToHost));
+    return POLAR_OK;
+}
+int polar_encode(polar_code_t *h, const uint8_t *info, uint8_t *coded) { return polar_encode_batch(h, info, 1, coded); }
+
+int polar_synth_llr_dev(polar_code_t *h, uint64_t seed, uint64_t trial0, long B, double s,
+                        double *d_llr, uint8_t *d_info, void *stream) {
+    if (!h || !d_llr) return fail(POLAR_E_ARG, "NULL argument");
+    if (B <= 0) return B == 0 ? POLAR_OK : fail(POLAR_E_ARG, "negative batch");
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    PolarEncodeParams p;
+    fill_enc(h, p);
+    p.B = B; p.seed = seed; p.trial0 = trial0; p.s = s; p.llr = d_llr; p.info_out = d_info;
+    HIP_TRY(polar_launch_synth(p, (hipStream_t)stream));
+    return POLAR_OK;
+}
+
+int polar_count_errors_dev(polar_code_t *h, const uint8_t *d_a, const uint8_t *d_b, long B,
+                           unsigned long long *d_err_count, void *stream) {
+    if (!h || !d_a || !d_b || !d_err_count) return fail(POLAR_E_ARG, "NULL argument");
+    if (B <= 0) return B == 0 ? POLAR_OK : fail(POLAR_E_ARG, "negative batch");
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    HIP_TRY(polar_launch_count_errors(d_a, d_b, B, h->K, d_err_count, nullptr, (hipStream_t)stream));
+    return POLAR_OK;
+}
+
+// ---- Monte-Carlo (PolarCode::get_bler_quick, PolarCode.cpp:658-785) -----------------------
+int polar_mc_batch(polar_code_t *h, uint64_t seed, uint64_t t0, long T, long stride,
+                   const double *ebno, int n_e, const uint8_t *Ls, int n_L,
+                   const uint8_t *enabled, uint64_t *err, uint64_t *run) {
+    if (!h || !ebno || !Ls || !enabled || !err || !run) return fail(POLAR_E_ARG, "NULL argument");
+    if (T <= 0 || stride <= 0 || n_e <= 0 || n_L <= 0) return fail(POLAR_E_ARG, "bad sizes");
+    for (int i = 0; i < n_L; ++i)
+        if (Ls[i] < 1 || Ls[i] > POLAR_MAX_LIST) return fail(POLAR_E_ARG, "list size %d out of range", (int)Ls[i]);
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    const int N = h->N, K = h->K;
+    if ((rc = h->d_in.ensure((size_t)T * N))) return rc;
+    if ((rc = h->d_out.ensure((size_t)T * K))) return rc;
+    if ((rc = h->d_bytes_a.ensure((size_t)T * K))) return rc;      // sent info
+    if ((rc = h->d_bytes_b.ensure((size_t)T))) return rc;          // mismatch flags
+    if ((rc = h->d_sel.ensure((size_t)T))) return rc;
+    std::vector<uint64_t> alive, next;
+    std::vector<uint8_t> flags((size_t)T);
+    for (int li = 0; li < n_L; ++li) {
+        // trials still to be simulated for this list size: every trial until it is decoded
+        // correctly at some (lower) Eb/N0 — the reference's prev_decoded hack (:732-742)
+        alive.resize((size_t)T);
+        for (long i = 0; i < T; ++i) alive[i] = t0 + (uint64_t)i * (uint64_t)stride;
+        for (int ie = 0; ie < n_e; ++ie) {
+            if (!enabled[li * n_e + ie]) continue;                     // :725
+            run[li * n_e + ie] += (uint64_t)T;                         // :728 (counted even when skipped)
+            const long A = (long)alive.size();
+            if (A == 0) continue;
+            HIP_TRY(hipMemcpy(h->d_sel.p, alive.data(), (size_t)A * sizeof(uint64_t), hipMemcpyHostToDevice));
+            PolarEncodeParams p;
+            fill_enc(h, p);
+            p.B = A; p.seed = seed; p.sel = h->d_sel.p; p.s = polar_snr_sqrt_linear(h, ebno[ie]);
+            p.llr = h->d_in.p; p.info_out = h->d_bytes_a.p;
+            HIP_TRY(polar_launch_synth(p, nullptr));
+            if ((rc = polar_decode_scl_llr_batch_dev(h, h->d_in.p, A, Ls[li], h->d_out.p, nullptr, nullptr))) return rc;
+            HIP_TRY(polar_launch_count_errors(h->d_out.p, h->d_bytes_a.p, A, K, nullptr, h->d_bytes_b.p, nullptr));
+            HIP_TRY(hipMemcpy(flags.data(), h->d_bytes_b.p, (size_t)A, hipMemcpyDeviceToHost));
+            next.clear();
+            for (long i = 0; i < A; ++i)
+                if (flags[i]) { err[li * n_e + ie]++; next.push_back(alive[i]); }   // :766-769
+            alive.swap(next);
+        }
+    }
+    return POLAR_OK;
+}
+
+int polar_get_bler_quick(polar_code_t *h, const double *ebno, int n_e, const uint8_t *Ls, int n_L,
+                         long max_runs, long max_err, uint64_t seed, long batch, double *bler_out) {
+    if (!h || !ebno || !Ls || !bler_out) return fail(POLAR_E_ARG, "NULL argument");
+    if (n_e <= 0 || n_L <= 0 || max_runs <= 0 || batch <= 0) return fail(POLAR_E_ARG, "bad sizes");
+    const int P = n_e * n_L;
+    std::vector<uint64_t> err(P, 0), run(P, 0);
+    std::vector<uint8_t> en(P, 1);
+    for (long t0 = 0; t0 < max_runs; t0 += batch) {
+        long T = std::min(batch, max_runs - t0);
+        bool any = false;
+        for (int i = 0; i < P; ++i) { en[i] = (err[i] <= (uint64_t)max_err); any |= en[i]; }   // :725
+        if (!any) break;
+        int rc = polar_mc_batch(h, seed, (uint64_t)t0, T, 1, ebno, n_e, Ls, n_L, en.data(), err.data(), run.data());
+        if (rc) return rc;
+    }
+    for (int i = 0; i < P; ++i) bler_out[i] = run[i] ? (double)err[i] / (double)run[i] : 0.0;    // :777-781
+    return POLAR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,43 @@
+// polar_kernels.h — launch interface between the C-ABI host code and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+struct PolarDecodeParams {
+    int n, N, K, crc, L;
+    int W;                       // 32-bit words of decision history = ceil((K+crc)/32)
+    long B;                      // codewords
+    const double *llr;           // [B][N] device
+    uint8_t *out;                // [B][K] device
+    double *pm_out;              // [B] device or nullptr
+    const uint8_t *frozen;       // [N] device
+    const uint16_t *info_rank;   // [K+crc] device: rank of order[beta] among the unfrozen positions
+    const uint32_t *crc_mask;    // [crc][W] device: parity masks over unfrozen ranks (check bit included)
+    double *llr_scr;             // per-wave scratch: [grid][N - 2*SL][64]
+    uint32_t *c_scr;             // per-wave scratch: [grid][2][N/32 - 2][64]
+    uint32_t *hist_scr;          // per-wave scratch: [grid][W][64]
+};
+
+size_t polar_decode_lds_bytes(int lds_log);
+hipError_t polar_launch_decode_llr(const PolarDecodeParams &p, int gs, int lds_log, int grid, hipStream_t st);
+
+struct PolarEncodeParams {
+    int n, N, K, crc;
+    long B;
+    const uint8_t *info;         // [B][K] device (encode) — unused by synth
+    uint8_t *coded;              // [B][N] device (encode) — optional for synth
+    const uint16_t *order;       // [N] device
+    const uint8_t *crcm;         // [crc][K] device
+    // synth
+    uint64_t seed, trial0;
+    long stride;                 // trial index = trial0 + b*stride, or sel[b] when sel != nullptr
+    const uint64_t *sel;
+    double s;
+    double *llr;                 // [B][N]
+    uint8_t *info_out;           // [B][K] or nullptr
+};
+hipError_t polar_launch_encode(const PolarEncodeParams &p, hipStream_t st);
+hipError_t polar_launch_synth(const PolarEncodeParams &p, hipStream_t st);
+hipError_t polar_launch_count_errors(const uint8_t *a, const uint8_t *b, long B, int K,
+                                     unsigned long long *err, uint8_t *mismatch_flags, hipStream_t st);

@@ -1,0 +1,434 @@
+// polar_kernels.hip — gfx950 (CDNA4) kernels for the polar SC/SCL hot path.
+//
+// Design: ONE LANE PER LIST PATH.  A wavefront (64 lanes) decodes
+// G = 64/GS codewords at once, GS = pow2ceil(L) lanes per codeword; lane `lig` of a group
+// IS path index `lig` of the reference (PolarCode.cpp's `l`).  All codewords and all paths
+// follow the same successive-cancellation schedule (it depends only on phi and the frozen
+// mask), so the 64 lanes run the N-step recursion in lockstep with no divergence; the only
+// cross-lane work is the fork/prune step (rank of 2L fork metrics, LIFO path-index stack,
+// clone = register shuffle).
+//
+// Memory: every per-path array is laid out [layer][element][lane] so that the 64 lanes of a
+// wave touch 64 consecutive doubles (512 B) — coalesced in HBM/L2, conflict-free in LDS.
+// The Tal-Vardy lazy copy (getArrayPointer_*, PolarCode.cpp:305-373) becomes a per-lane,
+// per-layer "slot pointer": a path WRITES its own slot (= its lane) and READS the slot its
+// pointer names; cloning copies the pointers (registers) only. Because a (layer) array is
+// always completely rewritten by all active paths in the same step, no copy-on-write and no
+// reference counting is needed, and a permutation of slots inside a group keeps the access
+// inside the same 512-byte row.
+//
+// Element order inside a layer is bit-reversed w.r.t. the reference (position j holds the
+// reference's beta = bitrev(j)), so that a node combines elements (j, j+S) and partial sums
+// are combined by word-wise XOR/concatenation instead of a bit interleave.
+//
+// Arithmetic is IEEE double with the reference's formulas and operation order
+// (PolarCode.cpp:437-451, 483, 505-506); build with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "polar_kernels.h"
+#include "polar_synth.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+// 16 one-byte slot pointers packed in two 64-bit registers, indexed by a wave-uniform i
+struct P16 {
+    u64 lo, hi;
+    __device__ __forceinline__ int get(int i) const {
+        return i < 8 ? (int)((lo >> (8 * i)) & 0xFFull) : (int)((hi >> (8 * (i - 8))) & 0xFFull);
+    }
+    __device__ __forceinline__ void set(int i, int v) {
+        if (i < 8) lo = (lo & ~(0xFFull << (8 * i))) | ((u64)(unsigned)v << (8 * i));
+        else hi = (hi & ~(0xFFull << (8 * (i - 8)))) | ((u64)(unsigned)v << (8 * (i - 8)));
+    }
+};
+
+// f-node (check node), exact + min-sum branches: PolarCode.cpp:437-446
+__device__ __forceinline__ double f_node(double a, double b) {
+    double fa = fabs(a), fb = fabs(b);
+    double mx = (fa < fb) ? fb : fa;
+    if (40 > mx) return log((exp(a + b) + 1) / (exp(a) + exp(b)));
+    double sg = (double)((a < 0) ? -1 : (a > 0)) * ((b < 0) ? -1 : (b > 0));
+    return sg * ((fb < fa) ? fb : fa);
+}
+// g-node: PolarCode.cpp:449-450  (1 - 2u)*a + b
+__device__ __forceinline__ double g_node(double a, double b, unsigned u) {
+    return (double)(1 - 2 * (int)u) * a + b;
+}
+// log(1 + exp(x)) exactly as written at PolarCode.cpp:483,505-506 (overflows to +inf for x > 709.78)
+__device__ __forceinline__ double softplus_ref(double x) { return log(1 + exp(x)); }
+
+__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl(lo, src, 64);
+    hi = __shfl(hi, src, 64);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ void wave_mem_fence() {
+    // lanes of one wave exchange data through LDS/global: keep the compiler from caching or
+    // reordering across this point (hardware executes a wave's memory ops in order)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+}  // namespace
+
+// Layer storage helpers --------------------------------------------------------------------
+// LDS:    layers with S <= SL; layer of size S starts at element (S-1); element e at [e*64 + lane]
+// global: layers with S >  SL; layer of size S starts at element (S-2*SL)
+//
+// GS  : lanes per codeword (power of two >= L)
+// LDS_LOG : log2 of the largest layer size kept in LDS
+template <int GS, int LDS_LOG>
+__global__ __launch_bounds__(64) void scl_decode_llr_kernel(PolarDecodeParams p) {
+    constexpr int G = 64 / GS;
+    constexpr int SL = 1 << LDS_LOG;
+    const int lane = threadIdx.x;
+    const int lig = lane & (GS - 1);   // path index l of the reference
+    const int gbase = lane & ~(GS - 1);
+    const int grp = lane / GS;
+    const int n = p.n, N = p.N, K = p.K, L = p.L;
+    const u64 gmask = (GS == 64) ? ~0ull : ((1ull << GS) - 1ull);
+    const u64 below = (1ull << lig) - 1ull;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *lds_llr = reinterpret_cast<double *>(smem);                        // [(2*SL-1)][64]
+    double *sortbuf = lds_llr + (size_t)(2 * SL - 1) * 64;                     // [128]
+    volatile unsigned char *stackv = reinterpret_cast<unsigned char *>(sortbuf + 128);   // [64]
+    volatile unsigned char *srcof = stackv + 64;                               // [64]
+
+    // per-wave global scratch
+    const size_t big_elems = (N > 2 * SL) ? (size_t)(N - 2 * SL) : 0;
+    double *g_llr = p.llr_scr + (size_t)blockIdx.x * big_elems * 64;
+    const int cwords = (N >= 128) ? (N / 32 - 2) : 0;                          // words of big C layers (S >= 64)
+    uint32_t *g_cl = p.c_scr + (size_t)blockIdx.x * 2 * (size_t)cwords * 64;
+    uint32_t *g_cr = g_cl + (size_t)cwords * 64;
+    uint32_t *g_hist = p.hist_scr + (size_t)blockIdx.x * (size_t)p.W * 64;
+
+    for (long g0 = (long)blockIdx.x * G; g0 < p.B; g0 += (long)gridDim.x * G) {
+        const long cw = g0 + grp;
+        const bool valid = (cw < p.B);
+        const double *in0 = p.llr + (size_t)(valid ? cw : 0) * N;
+
+        // initializeDataStructures + assignInitialPath (PolarCode.cpp:195-272): the inactive
+        // stack holds 0..L-1, the first pop (initial path) is L-1.
+        bool active = valid && (lig == L - 1);
+        double pm = 0.0;
+        int sp = L - 1;                            // group-uniform stack pointer
+        if (lig < L - 1) stackv[gbase + lig] = (unsigned char)lig;
+        P16 pL = {0, 0};                           // LLR slot pointer per layer (index sh = n - lam)
+        P16 pC = {0, 0};                           // column-0 C slot pointer for big layers (index sh)
+        u64 clsmall = 0;                           // column-0 partial sums of layers with S <= 32: bits [S, 2S)
+        uint32_t hword = 0;                        // decisions of the current 32 unfrozen steps
+        int origin = lig;                          // slot that holds this path's flushed history
+        unsigned t = 0;                            // unfrozen steps so far (wave-uniform)
+        wave_mem_fence();
+
+        for (int phi = 0; phi < N; ++phi) {
+            // ---------------- recursivelyCalcLLR(n, phi): PolarCode.cpp:422-455 ----------------
+            const int lam_top = phi ? (n - __builtin_ctz((unsigned)phi)) : 1;
+            double leaf = 0.0;
+            for (int lam = lam_top; lam <= n; ++lam) {
+                const int sh = n - lam;
+                const int S = 1 << sh;
+                const bool odd = (phi >> sh) & 1;
+                if (active) {
+                    // input layer lam-1 (size 2S): 0 = channel LLRs, else scratch/LDS slot
+                    const int pin = (lam > 1) ? pL.get(sh + 1) : 0;
+                    const double *inp;   // element j at inp[j*istride]
+                    size_t istride;
+                    const bool in_is_ch = (lam == 1);
+                    const bool in_lds = (!in_is_ch) && (2 * S <= SL);
+                    if (in_lds) inp = lds_llr + (size_t)(2 * S - 1) * 64 + gbase + pin;
+                    else if (!in_is_ch) inp = g_llr + (size_t)(2 * S - 2 * SL) * 64 + gbase + pin;
+                    else inp = nullptr;
+                    istride = 64;
+                    const bool out_lds = (S <= SL);
+                    double *outp = out_lds ? (lds_llr + (size_t)(S - 1) * 64 + lane)
+                                           : (g_llr + (size_t)(S - 2 * SL) * 64 + lane);
+                    // partial sums for g (column 0 of C_lam)
+                    uint32_t cbits = 0;
+                    const uint32_t *cwp = nullptr;
+                    if (odd) {
+                        if (S <= 32) cbits = (uint32_t)(clsmall >> S);
+                        else cwp = g_cl + (size_t)(S / 32 - 2) * 64 + gbase + pC.get(sh);
+                    }
+                    if (S >= 4) {
+                        for (int j = 0; j < S; j += 4) {
+                            double a[4], b[4], r[4];
+                            if (in_is_ch) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    // position j <-> reference beta = bitrev_n(j); (j, j+N/2) <-> (2b', 2b'+1)
+                                    unsigned idx = __brev((unsigned)(j + k)) >> (32 - n);
+                                    a[k] = in0[idx];
+                                    b[k] = in0[idx + 1];
+                                }
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    a[k] = inp[(size_t)(j + k) * istride];
+                                    b[k] = inp[(size_t)(j + k + S) * istride];
+                                }
+                            }
+                            if (odd) {
+                                if (S > 32 && (j & 31) == 0) cbits = cwp[(size_t)(j >> 5) * 64];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) r[k] = g_node(a[k], b[k], (cbits >> ((j + k) & 31)) & 1u);
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) r[k] = f_node(a[k], b[k]);
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) outp[(size_t)(j + k) * 64] = r[k];
+                        }
+                    } else {
+                        for (int j = 0; j < S; ++j) {
+                            double a, b;
+                            if (in_is_ch) {
+                                unsigned idx = __brev((unsigned)j) >> (32 - n);
+                                a = in0[idx];
+                                b = in0[idx + 1];
+                            } else {
+                                a = inp[(size_t)j * istride];
+                                b = inp[(size_t)(j + S) * istride];
+                            }
+                            double r = odd ? g_node(a, b, (cbits >> j) & 1u) : f_node(a, b);
+                            outp[(size_t)j * 64] = r;
+                            leaf = r;
+                        }
+                    }
+                    pL.set(sh, lig);
+                }
+                wave_mem_fence();
+            }
+
+            // ---------------- leaf: frozen / unfrozen ----------------
+            const bool frozen = p.frozen[phi] != 0;   // wave-uniform
+            unsigned ubit = 0;
+            if (frozen) {
+                // continuePaths_FrozenBit: PolarCode.cpp:475-487
+                if (active) pm += softplus_ref(-leaf);
+            } else {
+                // continuePaths_UnfrozenBit: PolarCode.cpp:489-607
+                double pf0 = __builtin_nan(""), pf1 = __builtin_nan("");
+                if (active) {
+                    pf0 = -(pm + softplus_ref(-leaf));
+                    pf1 = -(pm + softplus_ref(leaf));
+                }
+                const u64 actm = (__ballot(active) >> gbase) & gmask;
+                const int nact = __popcll(actm);
+                const int rho = (2 * nact < L) ? 2 * nact : L;
+                bool c0 = active, c1 = active;
+                const bool need = (2 * nact > L);          // otherwise every fork continues
+                if (__any(need)) {
+                    sortbuf[2 * lane] = pf0;
+                    sortbuf[2 * lane + 1] = pf1;
+                    wave_mem_fence();
+                    int r0 = 0, r1 = 0;
+                    const double *sb = sortbuf + 2 * gbase;
+                    const int i0 = 2 * lig, i1 = 2 * lig + 1;
+                    for (int i = 0; i < 2 * GS; ++i) {
+                        double v = sb[i];
+                        r0 += (v > pf0) || (v == pf0 && i < i0);
+                        r1 += (v > pf1) || (v == pf1 && i < i1);
+                    }
+                    if (need) {
+                        c0 = active && (r0 < rho);
+                        c1 = active && (r1 < rho);
+                    }
+                    wave_mem_fence();
+                }
+                // kills (ascending l) push, then clones (ascending l) pop: PolarCode.cpp:555-570
+                const bool kill = active && !c0 && !c1;
+                const bool both = c0 && c1;
+                const u64 km = (__ballot(kill) >> gbase) & gmask;
+                const u64 bm = (__ballot(both) >> gbase) & gmask;
+                srcof[lane] = (unsigned char)lig;
+                if (kill) stackv[gbase + sp + __popcll(km & below)] = (unsigned char)lig;
+                sp += __popcll(km);
+                wave_mem_fence();
+                if (both) {
+                    int lp = stackv[gbase + sp - 1 - __popcll(bm & below)];
+                    srcof[gbase + lp] = (unsigned char)lig;
+                }
+                sp -= __popcll(bm);
+                wave_mem_fence();
+                const int src = srcof[lane];
+                const bool is_clone = (src != lig);
+                // PM of the surviving forks: PM + log(1+exp(-+llr)) is the very sum whose negation
+                // was ranked (PolarCode.cpp:580-582, 593, 601)
+                double pm_new = c0 ? -pf0 : -pf1;
+                ubit = c0 ? 0u : 1u;
+                if (__any(is_clone)) {
+                    const int sl = gbase + src;
+                    double pm1 = shfl_d(-pf1, sl);
+                    u64 a0 = shfl_u64(pL.lo, sl), a1 = shfl_u64(pL.hi, sl);
+                    u64 b0 = shfl_u64(pC.lo, sl), b1 = shfl_u64(pC.hi, sl);
+                    u64 cs = shfl_u64(clsmall, sl);
+                    uint32_t hw = __shfl(hword, sl, 64);
+                    int og = __shfl(origin, sl, 64);
+                    if (is_clone) {
+                        pm_new = pm1; ubit = 1u;
+                        pL.lo = a0; pL.hi = a1; pC.lo = b0; pC.hi = b1;
+                        clsmall = cs; hword = hw; origin = og;
+                    }
+                }
+                active = (active && !kill) || is_clone;
+                if (active) {
+                    pm = pm_new;
+                    hword |= ubit << (t & 31);
+                } else {
+                    pm = 0.0;   // killPath zeroes the metric (PolarCode.cpp:293-294)
+                }
+                // history flush every 32 unfrozen steps: copy the flushed prefix from `origin`
+                if ((t & 31) == 31) {
+                    const int w = (int)(t >> 5);
+                    if (__any(active && origin != lig)) {
+                        for (int wi = 0; wi < w; ++wi) {
+                            uint32_t v = 0;
+                            if (active) v = g_hist[(size_t)wi * 64 + gbase + origin];
+                            wave_mem_fence();
+                            if (active) g_hist[(size_t)wi * 64 + lane] = v;
+                        }
+                    }
+                    if (active) { g_hist[(size_t)w * 64 + lane] = hword; origin = lig; hword = 0; }
+                    wave_mem_fence();
+                }
+                ++t;
+            }
+
+            // ---------------- partial sums ----------------
+            if ((phi & 1) == 0) {
+                // left leaf: column 0 of C_n (size 1) lives at bit 1 of clsmall
+                if (active) clsmall = (clsmall & ~2ull) | ((u64)ubit << 1);
+            } else {
+                // recursivelyUpdateC(n, phi): PolarCode.cpp:457-473. X = column 1 of C_lam.
+                int S = 1, ph = phi;
+                uint32_t X = ubit;   // valid while S <= 32
+                for (;;) {
+                    if (4 * S > N) break;                   // C_0 is never read (PolarCode.cpp writes it, nobody uses it)
+                    const int psi = ph >> 1;
+                    const bool to_right = (psi & 1);        // result becomes column 1 of C_{lam-1}
+                    const int sh = __builtin_ctz((unsigned)S);
+                    if (S <= 16) {
+                        uint32_t cl = (uint32_t)(clsmall >> S) & ((1u << S) - 1u);
+                        uint32_t nw = (cl ^ X) | (X << S);   // 2S bits
+                        if (!to_right) {
+                            const int S2 = 2 * S;
+                            const u64 m = ((S2 == 32) ? 0xFFFFFFFFull : ((1ull << S2) - 1ull)) << S2;
+                            if (active) clsmall = (clsmall & ~m) | ((u64)nw << S2);
+                        }
+                        X = nw;
+                    } else if (S == 32) {
+                        uint32_t cl = (uint32_t)(clsmall >> 32);
+                        uint32_t *dst = (to_right ? g_cr : g_cl) + (size_t)0 * 64 + lane;   // layer size 64 -> word offset 0
+                        if (active) { dst[0] = cl ^ X; dst[64] = X; }
+                        if (!to_right && active) pC.set(sh + 1, lig);
+                    } else {
+                        const int nwd = S / 32;
+                        const uint32_t *cl = g_cl + (size_t)(nwd - 2) * 64 + gbase + pC.get(sh);
+                        const uint32_t *cr = g_cr + (size_t)(nwd - 2) * 64 + lane;
+                        uint32_t *dst = (to_right ? g_cr : g_cl) + (size_t)(2 * nwd - 2) * 64 + lane;
+                        if (active) {
+                            for (int w = 0; w < nwd; ++w) {
+                                uint32_t r = cr[(size_t)w * 64];
+                                uint32_t l = cl[(size_t)w * 64];
+                                dst[(size_t)w * 64] = l ^ r;
+                                dst[(size_t)(w + nwd) * 64] = r;
+                            }
+                            if (!to_right) pC.set(sh + 1, lig);
+                        }
+                    }
+                    wave_mem_fence();
+                    if (!to_right) break;
+                    S *= 2;
+                    ph = psi;
+                }
+            }
+        }  // phi
+
+        // ---------------- final flush of the decision history ----------------
+        {
+            const int w = (int)(t >> 5);   // complete words
+            if (__any(active && origin != lig)) {
+                for (int wi = 0; wi < w; ++wi) {
+                    uint32_t v = 0;
+                    if (active) v = g_hist[(size_t)wi * 64 + gbase + origin];
+                    wave_mem_fence();
+                    if (active) g_hist[(size_t)wi * 64 + lane] = v;
+                }
+            }
+            if ((t & 31) != 0 && active) g_hist[(size_t)w * 64 + lane] = hword;
+            wave_mem_fence();
+        }
+        const int Wused = (int)((t + 31) >> 5);
+
+        // ---------------- findMostProbablePath + crc_check: PolarCode.cpp:609-644, 93-108 ----------------
+        bool pass = true;
+        if (p.crc > 0) {
+            uint32_t acc = 0;
+            if (active) {
+                for (int w = 0; w < Wused; ++w) {
+                    uint32_t hw = g_hist[(size_t)w * 64 + lane];
+                    for (int i = 0; i < p.crc; ++i)
+                        acc ^= (uint32_t)(__popc(hw & p.crc_mask[(size_t)i * p.W + w]) & 1) << i;
+                }
+            }
+            pass = (acc == 0);
+        }
+        const u64 passm = (__ballot(active && pass) >> gbase) & gmask;
+        const bool cand = active && (pass || passm == 0);      // :640-643 fall back to "no CRC"
+        double key = (cand && pm < 1.7976931348623157e308) ? pm : __builtin_inf();
+        int kidx = lig;
+#pragma unroll
+        for (int off = GS / 2; off >= 1; off >>= 1) {
+            double ok = shfl_d(key, lane ^ off);
+            int oi = __shfl(kidx, lane ^ off, 64);
+            if (ok < key || (ok == key && oi < kidx)) { key = ok; kidx = oi; }
+        }
+        // no candidate with PM < DBL_MAX: the reference returns l_p = 0 (PolarCode.cpp:611,626)
+        const int win = (key < __builtin_inf()) ? kidx : 0;
+        const double pm_win = shfl_d(pm, gbase + win);
+        if (valid) {
+            if (p.pm_out && lig == 0) p.pm_out[cw] = pm_win;
+            for (int b = lig; b < K; b += GS) {
+                unsigned r = p.info_rank[b];
+                uint32_t wd = g_hist[(size_t)(r >> 5) * 64 + gbase + win];
+                p.out[(size_t)cw * K + b] = (uint8_t)((wd >> (r & 31)) & 1u);
+            }
+        }
+        wave_mem_fence();
+    }  // codeword groups
+}
+
+// ------------------------------------------------------------------------------------------
+size_t polar_decode_lds_bytes(int lds_log) { return (size_t)((2u << lds_log) - 1) * 64 * 8 + 128 * 8 + 128; }
+
+template <int GS>
+static hipError_t launch_gs(const PolarDecodeParams &p, int lds_log, int grid, hipStream_t st) {
+    size_t lds = polar_decode_lds_bytes(lds_log);
+    switch (lds_log) {
+        case 3: hipLaunchKernelGGL((scl_decode_llr_kernel<GS, 3>), dim3(grid), dim3(64), lds, st, p); break;
+        case 4: hipLaunchKernelGGL((scl_decode_llr_kernel<GS, 4>), dim3(grid), dim3(64), lds, st, p); break;
+        case 5: hipLaunchKernelGGL((scl_decode_llr_kernel<GS, 5>), dim3(grid), dim3(64), lds, st, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t polar_launch_decode_llr(const PolarDecodeParams &p, int gs, int lds_log, int grid, hipStream_t st) {
+    switch (gs) {
+        case 1: return launch_gs<1>(p, lds_log, grid, st);
+        case 2: return launch_gs<2>(p, lds_log, grid, st);
+        case 4: return launch_gs<4>(p, lds_log, grid, st);
+        case 8: return launch_gs<8>(p, lds_log, grid, st);
+        case 16: return launch_gs<16>(p, lds_log, grid, st);
+        case 32: return launch_gs<32>(p, lds_log, grid, st);
+        case 64: return launch_gs<64>(p, lds_log, grid, st);
+        default: return hipErrorInvalidValue;
+    }
+}
