@@ -702,12 +702,12 @@ double orc_snr_sqrt_linear(void *h, double ebno_db) {
 }
 
 /* Batched Monte-Carlo on the synthetic workload — the CPU mirror of the GPU engine's
- * semantics (DESIGN.md "Monte-Carlo"): trials [t0, t0+T); per trial one noise vector shared
+ * semantics (DESIGN.md "Monte-Carlo"): trials {t0 + i*stride : i < T}; per trial one noise vector shared
  * by all (L, Eb/N0) (PolarCode.cpp:708-710); ascending Eb/N0 with the "decoded at a lower
  * Eb/N0 => counted as run, not simulated" hack (:728-742).  Early stop (:725) is evaluated
  * by the CALLER between batches (batch-granular), so this routine takes an `enabled` mask.
  * err/run are uint64 [n_L][n_e] accumulators. */
-void orc_mc_batch(void *h, uint64_t seed, uint64_t t0, long T, const double *ebno, int n_e,
+void orc_mc_batch(void *h, uint64_t seed, uint64_t t0, long T, long stride, const double *ebno, int n_e,
                   const uint8_t *Ls, int n_L, const uint8_t *enabled, uint64_t *err, uint64_t *run) {
     orc_t *c = (orc_t *)h;
     int N = c->N, K = c->K;
@@ -724,7 +724,7 @@ void orc_mc_batch(void *h, uint64_t seed, uint64_t t0, long T, const double *ebn
                 for (int j = 0; j < ie; ++j) if (prev[j]) run_sim = 0;
                 if (!run_sim) continue;
                 double s = orc_snr_sqrt_linear(h, ebno[ie]);
-                orc_synth_llr(h, seed, t0 + (uint64_t)t, s, llr, info);
+                orc_synth_llr(h, seed, t0 + (uint64_t)t * (uint64_t)stride, s, llr, info);
                 orc_decode_scl_llr(c, llr, Ls[li], dec, NULL);
                 int e = 0;
                 for (int i = 0; i < K; ++i) if (info[i] != dec[i]) { e = 1; break; }

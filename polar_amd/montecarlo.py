@@ -1,0 +1,63 @@
+"""Monte-Carlo BLER driver: PolarCode::get_bler_quick (PolarCode.cpp:658-785) sharded over GPUs.
+
+One process per GPU; rank r simulates trials {round_base + r + i*world}. Because the synthetic
+workload is counter-based (include/polar_synth.h), the union of trials — and therefore every
+counter — is independent of the world size. The only communication is one all-reduce (sum, int64)
+of the 2*n_L*n_e error/run counters per round (RCCL over xGMI when the backend is "nccl"); the
+early stop `num_err > max_err` (PolarCode.cpp:725) is evaluated on the reduced counters between
+rounds of `global_batch` trials.
+"""
+import numpy as np
+
+try:
+    import torch
+    import torch.distributed as dist
+except Exception:  # pragma: no cover
+    torch = None
+    dist = None
+
+
+def _world():
+    if dist is not None and dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def get_bler_quick_sharded(engine, ebno_vec, list_size_vec, max_runs=1000, max_err=100, seed=1,
+                           global_batch=None, device=None):
+    """engine(seed, t0, T, stride, ebno, Ls, enabled, err, run): adds this rank's counts into the
+    uint64 arrays err/run — polar_amd.PolarCode.mc_batch on a GPU. Returns (bler, err, run)."""
+    rank, world = _world()
+    ebno = np.ascontiguousarray(ebno_vec, np.float64)
+    Ls = np.ascontiguousarray(list_size_vec, np.uint8)
+    P = (len(Ls), len(ebno))
+    if global_batch is None:
+        global_batch = max_runs
+    if global_batch % world:
+        raise ValueError("global_batch must be a multiple of the world size")
+    err = np.zeros(P, np.uint64)
+    run = np.zeros(P, np.uint64)
+    base = 0
+    while base < max_runs:
+        gb = min(global_batch, max_runs - base)
+        enabled = (err <= np.uint64(max_err)).astype(np.uint8)            # PolarCode.cpp:725
+        if not enabled.any():
+            break
+        # trials base .. base+gb-1, round-robin over ranks
+        mine = len(range(rank, gb, world))
+        d_err = np.zeros(P, np.uint64)
+        d_run = np.zeros(P, np.uint64)
+        if mine:
+            engine(seed, base + rank, mine, world, ebno, Ls, enabled, d_err, d_run)
+        if world > 1:
+            t = torch.from_numpy(np.stack([d_err, d_run]).astype(np.int64))
+            if device is not None:
+                t = t.to(device)
+            dist.all_reduce(t)                                            # sum over ranks
+            t = t.cpu().numpy().astype(np.uint64)
+            d_err, d_run = t[0], t[1]
+        err += d_err
+        run += d_run
+        base += gb
+    bler = np.where(run > 0, err.astype(np.float64) / np.maximum(run, 1).astype(np.float64), 0.0)
+    return bler, err, run

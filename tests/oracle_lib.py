@@ -182,10 +182,10 @@ class Oracle(_Base):
                    _p(llr, _dp), _p(info, _u8p))
         return llr, info
 
-    def mc_batch(self, seed, t0, T, ebno, Ls, enabled, err, run):
+    def mc_batch(self, seed, t0, T, stride, ebno, Ls, enabled, err, run):
         ebno = np.ascontiguousarray(ebno, np.float64)
         Ls = np.ascontiguousarray(Ls, np.uint8)
         enabled = np.ascontiguousarray(enabled, np.uint8)
         assert err.dtype == np.uint64 and run.dtype == np.uint64
-        self._call("mc_batch", C.c_uint64(seed), C.c_uint64(t0), C.c_long(T), _p(ebno, _dp), C.c_int(len(ebno)),
+        self._call("mc_batch", C.c_uint64(seed), C.c_uint64(t0), C.c_long(T), C.c_long(stride), _p(ebno, _dp), C.c_int(len(ebno)),
                    _p(Ls, _u8p), C.c_int(len(Ls)), _p(enabled, _u8p), _p(err, _u64p), _p(run, _u64p))

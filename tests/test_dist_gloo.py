@@ -1,0 +1,58 @@
+"""CPU suite: the multi-GPU Monte-Carlo sharding logic (polar_amd/montecarlo.py) under
+torch.distributed with the gloo backend, world_size 2. The per-rank engine is the CPU oracle
+(test-only) standing in for the GPU engine: the sharded counters must equal the unsharded ones
+exactly, because the synthetic trials are counter-based."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys, json
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import ctypes as C
+import numpy as np
+import torch, torch.distributed as dist
+from oracle_lib import Oracle
+from polar_amd.montecarlo import get_bler_quick_sharded
+world = int(os.environ.get("WORLD_SIZE", "1"))
+if world > 1:
+    dist.init_process_group(backend="gloo")
+C.CDLL(None).srand(1)
+o = Oracle(7, 64, 0.32, 4)
+bler, err, run = get_bler_quick_sharded(o.mc_batch, [1.0, 2.5, 4.0], [1, 4], max_runs=96, max_err=10, seed=11, global_batch=24)
+if (not dist.is_initialized()) or dist.get_rank() == 0:
+    print("RESULT " + json.dumps({"err": err.tolist(), "run": run.tolist(), "bler": bler.tolist()}))
+if dist.is_initialized():
+    dist.destroy_process_group()
+"""
+
+
+def _run(world, tmp_path):
+    w = tmp_path / "worker.py"
+    w.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    if world == 1:
+        cmd = [sys.executable, str(w), ROOT]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", "29517", str(w), ROOT]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    import json
+    return json.loads(line[7:])
+
+
+def test_sharded_counters_equal_unsharded(oracle_built, tmp_path):
+    a = _run(1, tmp_path)
+    b = _run(2, tmp_path)
+    assert a == b
+    run = np.array(a["run"])
+    err = np.array(a["err"])
+    assert run.max() <= 96 and (err <= run).all() and run.min() >= 24
+    # early stop happened somewhere (low Eb/N0, max_err = 10) and not everywhere
+    assert (run < 96).any() and (run == 96).any()

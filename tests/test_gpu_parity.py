@@ -49,3 +49,115 @@ def test_decode_scl_llr_matches_oracle(built_lib, oracle_built, n, K, crc, L):
         got = g.decode_scl_llr(llr, L)
         bad = np.nonzero((want != got).any(axis=1))[0]
         assert bad.size == 0, f"{bad.size}/{B} codewords differ (first {bad[:5]}) n={n} K={K} crc={crc} L={L} ebno={ebno}"
+
+
+@pytest.mark.parametrize("L", [3, 5, 6, 12, 20, 33, 64])
+def test_odd_list_sizes_match_oracle(built_lib, oracle_built, L):
+    """The reference accepts any list size (not only powers of two)."""
+    o, g = _pair(9, 256, 8)
+    llr, _ = o.synth_llr(4321, 50, 40, o.snr_sqrt_linear(1.0))
+    assert (o.decode_scl_llr(llr, L) == g.decode_scl_llr(llr, L)).all()
+
+
+def test_ragged_batches_and_empty(built_lib, oracle_built):
+    o, g = _pair(8, 128, 4)
+    llr, _ = o.synth_llr(9, 0, 131, o.snr_sqrt_linear(1.5))
+    want = o.decode_scl_llr(llr, 8)
+    for B in (1, 2, 3, 7, 9, 63, 65, 131):       # not multiples of the codewords-per-wave
+        assert (g.decode_scl_llr(llr[:B], 8) == want[:B]).all()
+    assert g.decode_scl_llr(llr[:0], 8).shape == (0, 128)
+    # single-vector form
+    assert (g.decode_scl_llr(llr[5], 8) == want[5]).all()
+
+
+@pytest.mark.parametrize("lds_log", [3, 4, 5])
+def test_tuning_knobs_do_not_change_results(built_lib, oracle_built, lds_log):
+    o, g = _pair(11, 1024, 16)
+    llr, _ = o.synth_llr(77, 0, 16, o.snr_sqrt_linear(1.5))
+    g.set_tuning(waves_per_cu=4, lds_log=lds_log)
+    assert (g.decode_scl_llr(llr, 32) == o.decode_scl_llr(llr, 32)).all()
+
+
+def test_device_synth_is_bit_identical_to_oracle(built_lib, oracle_built):
+    import torch
+    o, g = _pair(10, 512, 8)
+    for ebno, t0 in ((0.0, 0), (2.5, 12345678901)):
+        s = o.snr_sqrt_linear(ebno)
+        llr, info = o.synth_llr(31337, t0, 300, s)
+        d_llr = torch.empty((300, 1024), dtype=torch.float64, device="cuda")
+        d_info = torch.empty((300, 512), dtype=torch.uint8, device="cuda")
+        g.synth_llr_dev(31337, t0, 300, s, d_llr.data_ptr(), d_info.data_ptr())
+        torch.cuda.synchronize()
+        assert (d_llr.cpu().numpy() == llr).all()
+        assert (d_info.cpu().numpy() == info).all()
+
+
+def test_monte_carlo_counters_match_oracle(built_lib, oracle_built):
+    """polar_mc_batch (GPU) vs the oracle's orc_mc_batch: identical error/run counters, including
+    the 'decoded at a lower Eb/N0 => counted, not simulated' rule and disabled points."""
+    o, g = _pair(8, 128, 4)
+    ebno, Ls = [0.5, 1.5, 2.5, 3.5], [1, 4, 16]
+    en = np.ones((3, 4), np.uint8)
+    en[1, 2] = 0
+    e1, r1 = np.zeros((3, 4), np.uint64), np.zeros((3, 4), np.uint64)
+    e2, r2 = np.zeros((3, 4), np.uint64), np.zeros((3, 4), np.uint64)
+    o.mc_batch(5, 3, 150, 2, ebno, Ls, en, e1, r1)
+    g.mc_batch(5, 3, 150, 2, ebno, Ls, en, e2, r2)
+    assert (e1 == e2).all() and (r1 == r2).all()
+    assert e1.sum() > 0
+    # get_bler_quick = batches + early stop; batch-size independent when nothing stops early
+    b1 = g.get_bler_quick(ebno, Ls, max_runs=120, max_err=10**9, seed=5, batch=40)
+    b2 = g.get_bler_quick(ebno, Ls, max_runs=120, max_err=10**9, seed=5, batch=120)
+    assert (b1 == b2).all()
+
+
+def test_full_size_properties_config2(built_lib):
+    """BASELINE config 2 at full size (N=2048, K=1024, L=1, batch 65536): size-independent
+    properties — noiseless round trip encode -> BPSK LLR -> decode == info, and decode of the
+    device-generated 2 dB batch agrees with the sent bits except for a plausible BLER."""
+    import torch
+    import polar_amd
+    g = polar_amd.PolarCode(11, 1024, 0.32, 0)
+    B, N, K = 65536, 2048, 1024
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    info = torch.randint(0, 2, (B, K), dtype=torch.uint8, device="cuda", generator=gen)
+    coded = torch.empty((B, N), dtype=torch.uint8, device="cuda")
+    g.encode_dev(info.data_ptr(), B, coded.data_ptr())
+    llr = (1.0 - 2.0 * coded.to(torch.float64)) * 6.0        # bit 0 -> +6, bit 1 -> -6
+    out = torch.empty((B, K), dtype=torch.uint8, device="cuda")
+    g.decode_scl_llr_dev(llr.data_ptr(), B, 1, out.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(out, info)
+    # linearity of the encoder: enc(a ^ b) = enc(a) ^ enc(b)
+    c2 = torch.empty_like(coded)
+    g.encode_dev((info ^ info.roll(1, 0)).contiguous().data_ptr(), B, c2.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(c2, coded ^ coded.roll(1, 0))
+    # noisy batch: BLER at 2 dB for SC is ~0.05 (results/polar_performance.jpeg; golden table 0.052)
+    sent = torch.empty((B, K), dtype=torch.uint8, device="cuda")
+    g.synth_llr_dev(99, 0, B, g.snr_sqrt_linear(2.0), llr.data_ptr(), sent.data_ptr())
+    g.decode_scl_llr_dev(llr.data_ptr(), B, 1, out.data_ptr())
+    torch.cuda.synchronize()
+    bler = (out != sent).any(dim=1).double().mean().item()
+    assert 0.035 < bler < 0.07, bler
+
+
+def test_full_size_roundtrip_config4(built_lib):
+    """N=2048 K=1024 crc16 L=32: noiseless round trip and erasure-like robustness on 4096 codewords."""
+    import ctypes as C
+    import torch
+    import polar_amd
+    C.CDLL(None).srand(C.c_uint(1))
+    g = polar_amd.PolarCode(11, 1024, 0.32, 16)
+    B, N, K = 4096, 2048, 1024
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    info = torch.randint(0, 2, (B, K), dtype=torch.uint8, device="cuda", generator=gen)
+    coded = torch.empty((B, N), dtype=torch.uint8, device="cuda")
+    g.encode_dev(info.data_ptr(), B, coded.data_ptr())
+    llr = (1.0 - 2.0 * coded.to(torch.float64)) * 4.0
+    er = torch.rand((B, N), device="cuda", generator=gen) < 0.2      # 20% erasures (llr = 0)
+    llr = torch.where(er, torch.zeros_like(llr), llr).contiguous()
+    out = torch.empty((B, K), dtype=torch.uint8, device="cuda")
+    g.decode_scl_llr_dev(llr.data_ptr(), B, 32, out.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(out, info)
