@@ -76,7 +76,7 @@ struct polar_code {
     DevBuf<uint8_t> d_frozen, d_crcm;
     DevBuf<uint16_t> d_order, d_info_rank;
     DevBuf<uint32_t> d_crc_mask;
-    DevBuf<double> d_llr_scr;
+    DevBuf<double> d_llr_scr, d_tabs;
     DevBuf<uint32_t> d_c_scr, d_hist_scr;
     // staging for the host-pointer entry points
     DevBuf<double> d_in;
@@ -158,6 +158,15 @@ int ensure_device(polar_code *h) {
     if ((rc = upload(h->d_info_rank, h->info_rank))) return rc;
     if ((rc = upload(h->d_crc_mask, h->crc_mask))) return rc;
     if ((rc = upload(h->d_crcm, h->crcm))) return rc;
+    {   // tables of the fp64 exp/log routines (polar_kernels.hip): T[64], RC[129], LC[129]
+        std::vector<double> t(322);
+        for (int j = 0; j < 64; ++j) t[j] = std::exp2(-(double)j / 64.0);
+        for (int j = 0; j <= 128; ++j) {
+            t[64 + j] = 1.0 / (1.0 + (double)j / 128.0);
+            t[64 + 129 + j] = std::log1p((double)j / 128.0);
+        }
+        if ((rc = upload(h->d_tabs, t))) return rc;
+    }
     h->dev_ready = true;
     return POLAR_OK;
 }
@@ -234,7 +243,7 @@ void polar_destroy(polar_code_t *h) {
     if (!h) return;
     if (h->dev_ready) (void)hipSetDevice(h->device);
     h->d_frozen.release(); h->d_crcm.release(); h->d_order.release(); h->d_info_rank.release();
-    h->d_crc_mask.release(); h->d_llr_scr.release(); h->d_c_scr.release(); h->d_hist_scr.release();
+    h->d_crc_mask.release(); h->d_tabs.release(); h->d_llr_scr.release(); h->d_c_scr.release(); h->d_hist_scr.release();
     h->d_in.release(); h->d_out.release(); h->d_bytes_a.release(); h->d_bytes_b.release();
     h->d_counter.release(); h->d_sel.release();
     delete h;
@@ -318,7 +327,7 @@ int polar_decode_scl_llr_batch_dev(polar_code_t *h, const double *d_llr, long B,
     PolarDecodeParams p;
     p.n = h->n; p.N = h->N; p.K = h->K; p.crc = h->crc; p.L = L; p.W = h->W; p.B = B;
     p.llr = d_llr; p.out = d_out; p.pm_out = d_pm;
-    p.frozen = h->d_frozen.p; p.info_rank = h->d_info_rank.p; p.crc_mask = h->d_crc_mask.p;
+    p.frozen = h->d_frozen.p; p.info_rank = h->d_info_rank.p; p.crc_mask = h->d_crc_mask.p; p.tabs = h->d_tabs.p;
     p.llr_scr = h->d_llr_scr.p; p.c_scr = h->d_c_scr.p; p.hist_scr = h->d_hist_scr.p;
     HIP_TRY(polar_launch_decode_llr(p, gs, lds_log, grid, (hipStream_t)stream));
     return POLAR_OK;

@@ -14,6 +14,7 @@ struct PolarDecodeParams {
     const uint8_t *frozen;       // [N] device
     const uint16_t *info_rank;   // [K+crc] device: rank of order[beta] among the unfrozen positions
     const uint32_t *crc_mask;    // [crc][W] device: parity masks over unfrozen ranks (check bit included)
+    const double *tabs;          // [322] device: T[64] = 2^(-j/64), RC[129] = 1/(1+j/128), LC[129] = log(1+j/128)
     double *llr_scr;             // per-wave scratch: [grid][N - 2*SL][64]
     uint32_t *c_scr;             // per-wave scratch: [grid][2][N/32 - 2][64]
     uint32_t *hist_scr;          // per-wave scratch: [grid][W][64]

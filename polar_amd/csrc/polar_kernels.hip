@@ -45,20 +45,75 @@ struct P16 {
     }
 };
 
+// ---- fp64 transcendentals for the f-node and the path metric --------------------------------
+// The reference evaluates log((e^(a+b)+1)/(e^a+e^b)) and log(1+e^x) with libm. Bit-identity with
+// glibc's exp/log is not reachable on a GPU (ocml differs in the last ulp as well); what parity
+// needs is that every DECISION (sign of a leaf LLR, order of path metrics) is the reference's,
+// i.e. an absolute accuracy far below any decision margin. These routines keep ~1e-16 absolute
+// accuracy (the rounding level of the reference's own 1+e^x) at ~1/3 of the instruction count
+// of the libm-style sequence, using two small LDS tables (no division):
+//   exp(-x) = T[k&63] * 2^-(k>>6) * p5(-r),  x = k*ln2/64 + r
+//   log(m)  = LC[j] + log1p((m - c_j)/c_j),   c_j = 1 + j/128, j = rint((m-1)*128)
+// and the identity  f(a,b) = sgn(a)sgn(b)min(|a|,|b|) + h(|a+b|) - h(|a-b|),  h(x) = log1p(e^-x).
+// Structural exactness is preserved: h(x) == 0 exactly for x >= 36.74 (where the reference's
+// 1+e^-x rounds to 1), f(0,b) == 0 exactly, f is symmetric, log(1+e^x) -> +inf for x > 709.78.
+struct Tabs { const double *T, *RC, *LC; };   // LDS: T[64], RC[129], LC[129]
+
+__device__ __forceinline__ double exp_neg(double x, const Tabs &tb) {   // e^-x, x >= 0
+    const double kd = __builtin_rint(x * 92.332482616893657);            // 64/ln2
+    const int k = (int)kd;
+    double r = __builtin_fma(kd, -0.010830424696223417, x);              // ln2/64, high part (low 16 bits zero)
+    r = __builtin_fma(kd, -2.5728046223276688e-14, r);                   // ln2/64, low part
+    double p = __builtin_fma(r, -1.0 / 120.0, 1.0 / 24.0);
+    p = __builtin_fma(p, r, -1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, -1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(tb.T[k & 63] * p, -(k >> 6));
+}
+__device__ __forceinline__ double log_1p2(double m, const Tabs &tb) {    // log(m), m in [1,2]
+    const double jd = __builtin_rint((m - 1.0) * 128.0);
+    const int j = (int)jd;
+    const double c = __builtin_fma(jd, 0.0078125, 1.0);
+    const double q = (m - c) * tb.RC[j];
+    double p = __builtin_fma(q, -1.0 / 6.0, 0.2);
+    p = __builtin_fma(p, q, -0.25);
+    p = __builtin_fma(p, q, 1.0 / 3.0);
+    p = __builtin_fma(p, q, -0.5);
+    p = __builtin_fma(p, q, 1.0);
+    return __builtin_fma(q, p, tb.LC[j]);
+}
+__device__ __forceinline__ double h_fn(double x, const Tabs &tb) {       // log1p(e^-x), x >= 0
+    return log_1p2(1.0 + exp_neg(x, tb), tb);
+}
 // f-node (check node), exact + min-sum branches: PolarCode.cpp:437-446
-__device__ __forceinline__ double f_node(double a, double b) {
-    double fa = fabs(a), fb = fabs(b);
-    double mx = (fa < fb) ? fb : fa;
-    if (40 > mx) return log((exp(a + b) + 1) / (exp(a) + exp(b)));
-    double sg = (double)((a < 0) ? -1 : (a > 0)) * ((b < 0) ? -1 : (b > 0));
-    return sg * ((fb < fa) ? fb : fa);
+__device__ __forceinline__ double f_node(double a, double b, const Tabs &tb) {
+    const double fa = fabs(a), fb = fabs(b);
+    const double mx = (fa < fb) ? fb : fa;
+    const double mn = (fb < fa) ? fb : fa;
+    if (40 > mx) {
+        // |f| <= min(|a|,|b|): when that is within a few orders of the rounding noise (1e-16) the
+        // reference's result IS its rounding noise (e.g. exactly 0 once e^a, e^b round to 1), so the
+        // literal expression is evaluated for those (physically never occurring) elements.
+        if (mn < 9.5367431640625e-07) return log((exp(a + b) + 1) / (exp(a) + exp(b)));
+        const double base = ((a < 0) != (b < 0)) ? -mn : mn;
+        return base + (h_fn(fabs(a + b), tb) - h_fn(fabs(a - b), tb));
+    }
+    const double sg = (double)((a < 0) ? -1 : (a > 0)) * ((b < 0) ? -1 : (b > 0));
+    return sg * mn;
 }
 // g-node: PolarCode.cpp:449-450  (1 - 2u)*a + b
 __device__ __forceinline__ double g_node(double a, double b, unsigned u) {
     return (double)(1 - 2 * (int)u) * a + b;
 }
-// log(1 + exp(x)) exactly as written at PolarCode.cpp:483,505-506 (overflows to +inf for x > 709.78)
-__device__ __forceinline__ double softplus_ref(double x) { return log(1 + exp(x)); }
+// log(1 + exp(x)) of PolarCode.cpp:483,505-506: +inf for x > 709.78 (fp64 exp overflow), exactly
+// 0 for x <= -36.74
+__device__ __forceinline__ double softplus_ref(double x, const Tabs &tb) {
+    if (x > 709.782712893384) return __builtin_inf();
+    if (fabs(x) < 9.5367431640625e-07) return log(1 + exp(x));    // noise regime: literal (see f_node)
+    const double hx = h_fn(fabs(x), tb);
+    return (x > 0) ? x + hx : hx;
+}
 
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
@@ -97,8 +152,11 @@ __global__ __launch_bounds__(64) void scl_decode_llr_kernel(PolarDecodeParams p)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *lds_llr = reinterpret_cast<double *>(smem);                        // [(2*SL-1)][64]
     double *sortbuf = lds_llr + (size_t)(2 * SL - 1) * 64;                     // [128]
-    volatile unsigned char *stackv = reinterpret_cast<unsigned char *>(sortbuf + 128);   // [64]
+    double *tabs = sortbuf + 128;                                              // T[64] RC[129] LC[129] (+2 pad)
+    volatile unsigned char *stackv = reinterpret_cast<unsigned char *>(tabs + 324);      // [64]
     volatile unsigned char *srcof = stackv + 64;                               // [64]
+    for (int i = lane; i < 322; i += 64) tabs[i] = p.tabs[i];
+    const Tabs tb = {tabs, tabs + 64, tabs + 64 + 129};
 
     // per-wave global scratch
     const size_t big_elems = (N > 2 * SL) ? (size_t)(N - 2 * SL) : 0;
@@ -180,7 +238,7 @@ __global__ __launch_bounds__(64) void scl_decode_llr_kernel(PolarDecodeParams p)
                                 for (int k = 0; k < 4; ++k) r[k] = g_node(a[k], b[k], (cbits >> ((j + k) & 31)) & 1u);
                             } else {
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) r[k] = f_node(a[k], b[k]);
+                                for (int k = 0; k < 4; ++k) r[k] = f_node(a[k], b[k], tb);
                             }
 #pragma unroll
                             for (int k = 0; k < 4; ++k) outp[(size_t)(j + k) * 64] = r[k];
@@ -196,7 +254,7 @@ __global__ __launch_bounds__(64) void scl_decode_llr_kernel(PolarDecodeParams p)
                                 a = inp[(size_t)j * istride];
                                 b = inp[(size_t)(j + S) * istride];
                             }
-                            double r = odd ? g_node(a, b, (cbits >> j) & 1u) : f_node(a, b);
+                            double r = odd ? g_node(a, b, (cbits >> j) & 1u) : f_node(a, b, tb);
                             outp[(size_t)j * 64] = r;
                             leaf = r;
                         }
@@ -211,13 +269,13 @@ __global__ __launch_bounds__(64) void scl_decode_llr_kernel(PolarDecodeParams p)
             unsigned ubit = 0;
             if (frozen) {
                 // continuePaths_FrozenBit: PolarCode.cpp:475-487
-                if (active) pm += softplus_ref(-leaf);
+                if (active) pm += softplus_ref(-leaf, tb);
             } else {
                 // continuePaths_UnfrozenBit: PolarCode.cpp:489-607
                 double pf0 = __builtin_nan(""), pf1 = __builtin_nan("");
                 if (active) {
-                    pf0 = -(pm + softplus_ref(-leaf));
-                    pf1 = -(pm + softplus_ref(leaf));
+                    pf0 = -(pm + softplus_ref(-leaf, tb));
+                    pf1 = -(pm + softplus_ref(leaf, tb));
                 }
                 const u64 actm = (__ballot(active) >> gbase) & gmask;
                 const int nact = __popcll(actm);
@@ -406,7 +464,7 @@ __global__ __launch_bounds__(64) void scl_decode_llr_kernel(PolarDecodeParams p)
 }
 
 // ------------------------------------------------------------------------------------------
-size_t polar_decode_lds_bytes(int lds_log) { return (size_t)((2u << lds_log) - 1) * 64 * 8 + 128 * 8 + 128; }
+size_t polar_decode_lds_bytes(int lds_log) { return (size_t)((2u << lds_log) - 1) * 64 * 8 + 128 * 8 + 324 * 8 + 128; }
 
 template <int GS>
 static hipError_t launch_gs(const PolarDecodeParams &p, int lds_log, int grid, hipStream_t st) {
