@@ -272,14 +272,39 @@ __global__ __launch_bounds__(64) void scl_decode_llr_kernel(PolarDecodeParams p)
                 if (active) pm += softplus_ref(-leaf, tb);
             } else {
                 // continuePaths_UnfrozenBit: PolarCode.cpp:489-607
+                const u64 actm = (__ballot(active) >> gbase) & gmask;
+                const int nact = __popcll(actm);
+                const int rho = (2 * nact < L) ? 2 * nact : L;
+                // ---- fast path (exact): list full and every "good" fork (the bit the leaf LLR favours)
+                // beats every "bad" fork of every path => the L survivors are the L good forks, nobody
+                // is killed or cloned.  good metric = PM + log(1+e^-|llr|) (the same sum the general
+                // path computes); bad metric = PM + log(1+e^|llr|) >= (PM + |llr|)(1 - 2^-40).
+                const double al = fabs(leaf);
+                double gm = -__builtin_inf(), bl = __builtin_inf();
+                if (active) {
+                    gm = pm + softplus_ref(-al, tb);
+                    bl = (pm + al) * 0.99999999999909050530;
+                }
+                double gmax = gm, bmin = bl;
+#pragma unroll
+                for (int off = GS / 2; off >= 1; off >>= 1) {
+                    double og = shfl_d(gmax, lane ^ off), ob = shfl_d(bmin, lane ^ off);
+                    gmax = (og > gmax) ? og : gmax;
+                    bmin = (ob < bmin) ? ob : bmin;
+                }
+                const bool fastok = (nact == 0) || (nact == L && gmax < bmin);
+                if (__all(fastok)) {
+                    if (active) {
+                        ubit = (leaf < 0) ? 1u : 0u;
+                        pm = gm;
+                        hword |= ubit << (t & 31);
+                    }
+                } else {
                 double pf0 = __builtin_nan(""), pf1 = __builtin_nan("");
                 if (active) {
                     pf0 = -(pm + softplus_ref(-leaf, tb));
                     pf1 = -(pm + softplus_ref(leaf, tb));
                 }
-                const u64 actm = (__ballot(active) >> gbase) & gmask;
-                const int nact = __popcll(actm);
-                const int rho = (2 * nact < L) ? 2 * nact : L;
                 bool c0 = active, c1 = active;
                 const bool need = (2 * nact > L);          // otherwise every fork continues
                 if (__any(need)) {
@@ -288,11 +313,14 @@ __global__ __launch_bounds__(64) void scl_decode_llr_kernel(PolarDecodeParams p)
                     wave_mem_fence();
                     int r0 = 0, r1 = 0;
                     const double *sb = sortbuf + 2 * gbase;
-                    const int i0 = 2 * lig, i1 = 2 * lig + 1;
+                    const int i0 = 2 * lig;
+                    // stable rank: value descending, fork index 2l+b ascending on ties
+                    // (PolarCode.cpp:528-553: "> threshold" first, then "== threshold" in index order)
+#pragma unroll 4
                     for (int i = 0; i < 2 * GS; ++i) {
-                        double v = sb[i];
-                        r0 += (v > pf0) || (v == pf0 && i < i0);
-                        r1 += (v > pf1) || (v == pf1 && i < i1);
+                        const double v = sb[i];
+                        r0 += (i < i0) ? (v >= pf0) : (v > pf0);
+                        r1 += (i <= i0) ? (v >= pf1) : (v > pf1);
                     }
                     if (need) {
                         c0 = active && (r0 < rho);
@@ -342,6 +370,7 @@ __global__ __launch_bounds__(64) void scl_decode_llr_kernel(PolarDecodeParams p)
                 } else {
                     pm = 0.0;   // killPath zeroes the metric (PolarCode.cpp:293-294)
                 }
+                }   // general path
                 // history flush every 32 unfrozen steps: copy the flushed prefix from `origin`
                 if ((t & 31) == 31) {
                     const int w = (int)(t >> 5);
