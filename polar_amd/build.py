@@ -43,35 +43,42 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, profile=False):
+    """profile=True builds the instrumented variant libpolar_amd_prof.so (-DPOLAR_PROFILE: per-phase
+    cycle counters, tools/phase_profile.py); never used by the product path."""
+    global LIB
     os.makedirs(BUILD, exist_ok=True)
+    lib_out = os.path.join(HERE, "libpolar_amd_prof.so") if profile else LIB
+    tag = ".prof" if profile else ""
     headers = [os.path.join(INC, f) for f in os.listdir(INC)] + \
               [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     objs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(BUILD, s + ".o")
+        obj = os.path.join(BUILD, s + tag + ".o")
         objs.append(obj)
         if force or _newer(obj, [src] + headers + [os.path.abspath(__file__)]):
             cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                    "-Wall", "-Wno-unused-function", "-x", "hip", "-I", INC, "-I", CSRC, "-c", src, "-o", obj]
+            if profile:
+                cmd.insert(1, "-DPOLAR_PROFILE")
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
-    if force or _newer(LIB, objs):
+    if force or _newer(lib_out, objs):
         tl = _torch_lib()
-        cmd = [_hipcc(), "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [_hipcc(), "-shared", "-fPIC", "-o", lib_out] + objs
         if tl:
             # hipcc would add -L/opt/rocm/lib -lamdhip64 itself; link by hand instead so the
             # DT_NEEDED entry is the un-versioned name torch's copy is loaded under
             clang = "/opt/rocm/lib/llvm/bin/clang++"
-            cmd = [clang, "-shared", "-fPIC", "-o", LIB] + objs + \
+            cmd = [clang, "-shared", "-fPIC", "-o", lib_out] + objs + \
                   ["-L" + tl, "-lamdhip64", "-Wl,-rpath," + tl, "-Wl,-rpath,/opt/rocm/lib", "-lstdc++", "-lm"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    return LIB
+    return lib_out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, profile="--profile" in sys.argv))

@@ -29,6 +29,16 @@
 #include "polar_kernels.h"
 #include "polar_synth.h"
 
+#ifdef POLAR_PROFILE
+#define PROF_DECL u64 prof_acc[8] = {0,0,0,0,0,0,0,0}; u64 prof_t = __builtin_readcyclecounter();
+#define PROF(i) { u64 t_ = __builtin_readcyclecounter(); prof_acc[i] += t_ - prof_t; prof_t = t_; }
+#define PROF_OUT if (lane == 0 && p.pm_out) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd((u64 *)p.pm_out + i_, prof_acc[i_]); }
+#else
+#define PROF_DECL
+#define PROF(i)
+#define PROF_OUT
+#endif
+
 namespace {
 
 typedef unsigned long long u64;
@@ -86,6 +96,10 @@ __device__ __forceinline__ double log_1p2(double m, const Tabs &tb) {    // log(
 __device__ __forceinline__ double h_fn(double x, const Tabs &tb) {       // log1p(e^-x), x >= 0
     return log_1p2(1.0 + exp_neg(x, tb), tb);
 }
+__device__ __attribute__((noinline)) double f_literal(double a, double b) {
+    return log((exp(a + b) + 1) / (exp(a) + exp(b)));
+}
+__device__ __attribute__((noinline)) double softplus_literal(double x) { return log(1 + exp(x)); }
 // f-node (check node), exact + min-sum branches: PolarCode.cpp:437-446
 __device__ __forceinline__ double f_node(double a, double b, const Tabs &tb) {
     const double fa = fabs(a), fb = fabs(b);
@@ -95,7 +109,7 @@ __device__ __forceinline__ double f_node(double a, double b, const Tabs &tb) {
         // |f| <= min(|a|,|b|): when that is within a few orders of the rounding noise (1e-16) the
         // reference's result IS its rounding noise (e.g. exactly 0 once e^a, e^b round to 1), so the
         // literal expression is evaluated for those (physically never occurring) elements.
-        if (mn < 9.5367431640625e-07) return log((exp(a + b) + 1) / (exp(a) + exp(b)));
+        if (mn < 9.5367431640625e-07) return f_literal(a, b);
         const double base = ((a < 0) != (b < 0)) ? -mn : mn;
         return base + (h_fn(fabs(a + b), tb) - h_fn(fabs(a - b), tb));
     }
@@ -110,7 +124,7 @@ __device__ __forceinline__ double g_node(double a, double b, unsigned u) {
 // 0 for x <= -36.74
 __device__ __forceinline__ double softplus_ref(double x, const Tabs &tb) {
     if (x > 709.782712893384) return __builtin_inf();
-    if (fabs(x) < 9.5367431640625e-07) return log(1 + exp(x));    // noise regime: literal (see f_node)
+    if (fabs(x) < 9.5367431640625e-07) return softplus_literal(x);   // noise regime: literal (see f_node)
     const double hx = h_fn(fabs(x), tb);
     return (x > 0) ? x + hx : hx;
 }
@@ -121,6 +135,26 @@ __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
     lo = __shfl(lo, src, 64);
     hi = __shfl(hi, src, 64);
     return ((u64)hi << 32) | lo;
+}
+// cross-lane max/min over the GS lanes of a group: DPP inside a row of 16 (quad xor1, xor2,
+// half-mirror, mirror), ds_bpermute across rows
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int GS, bool MAX>
+__device__ __forceinline__ double group_reduce(double v, int lane) {
+    auto op = [](double a, double b) { return MAX ? ((b > a) ? b : a) : ((b < a) ? b : a); };
+    if (GS >= 2) v = op(v, dpp_d<0xB1>(v));      // quad_perm [1,0,3,2]
+    if (GS >= 4) v = op(v, dpp_d<0x4E>(v));      // quad_perm [2,3,0,1]
+    if (GS >= 8) v = op(v, dpp_d<0x141>(v));     // row_half_mirror
+    if (GS >= 16) v = op(v, dpp_d<0x140>(v));    // row_mirror
+    if (GS >= 32) v = op(v, __shfl(v, lane ^ 16, 64));
+    if (GS >= 64) v = op(v, __shfl(v, lane ^ 32, 64));
+    return v;
 }
 __device__ __forceinline__ void wave_mem_fence() {
     // lanes of one wave exchange data through LDS/global: keep the compiler from caching or
@@ -185,7 +219,9 @@ __global__ __launch_bounds__(64) void scl_decode_llr_kernel(PolarDecodeParams p)
         unsigned t = 0;                            // unfrozen steps so far (wave-uniform)
         wave_mem_fence();
 
+        PROF_DECL
         for (int phi = 0; phi < N; ++phi) {
+            PROF(0)
             // ---------------- recursivelyCalcLLR(n, phi): PolarCode.cpp:422-455 ----------------
             const int lam_top = phi ? (n - __builtin_ctz((unsigned)phi)) : 1;
             double leaf = 0.0;
@@ -214,13 +250,54 @@ __global__ __launch_bounds__(64) void scl_decode_llr_kernel(PolarDecodeParams p)
                         if (S <= 32) cbits = (uint32_t)(clsmall >> S);
                         else cwp = g_cl + (size_t)(S / 32 - 2) * 64 + gbase + pC.get(sh);
                     }
-                    if (S >= 4) {
+                    if (S >= 16 && !in_lds) {
+                        // source in HBM/L2 (channel LLRs or a scratch layer): software-pipelined,
+                        // 8 elements (16 loads, 8 KiB per wave) in flight ahead of the compute
+                        constexpr int U = 8;
+                        double a0[U], b0[U], a1[U], b1[U];
+                        auto load = [&](int j, double (&a)[U], double (&b)[U]) {
+                            if (in_is_ch) {
+#pragma unroll
+                                for (int k = 0; k < U; ++k) {
+                                    // position j <-> reference beta = bitrev_n(j); (j, j+N/2) <-> (2b', 2b'+1)
+                                    unsigned idx = __brev((unsigned)(j + k)) >> (32 - n);
+                                    a[k] = in0[idx];
+                                    b[k] = in0[idx + 1];
+                                }
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < U; ++k) {
+                                    a[k] = inp[(size_t)(j + k) * 64];
+                                    b[k] = inp[(size_t)(j + k + S) * 64];
+                                }
+                            }
+                        };
+                        auto comp = [&](int j, double (&a)[U], double (&b)[U]) {
+                            double r[U];
+                            if (odd) {
+                                if (S > 32 && (j & 31) == 0) cbits = cwp[(size_t)(j >> 5) * 64];
+#pragma unroll
+                                for (int k = 0; k < U; ++k) r[k] = g_node(a[k], b[k], (cbits >> ((j + k) & 31)) & 1u);
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < U; ++k) r[k] = f_node(a[k], b[k], tb);
+                            }
+#pragma unroll
+                            for (int k = 0; k < U; ++k) outp[(size_t)(j + k) * 64] = r[k];
+                        };
+                        load(0, a0, b0);
+                        for (int j = 0; j < S; j += 2 * U) {
+                            load(j + U, a1, b1);
+                            comp(j, a0, b0);
+                            if (j + 2 * U < S) load(j + 2 * U, a0, b0);
+                            comp(j + U, a1, b1);
+                        }
+                    } else if (S >= 4) {
                         for (int j = 0; j < S; j += 4) {
                             double a[4], b[4], r[4];
                             if (in_is_ch) {
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) {
-                                    // position j <-> reference beta = bitrev_n(j); (j, j+N/2) <-> (2b', 2b'+1)
                                     unsigned idx = __brev((unsigned)(j + k)) >> (32 - n);
                                     a[k] = in0[idx];
                                     b[k] = in0[idx + 1];
@@ -262,6 +339,7 @@ __global__ __launch_bounds__(64) void scl_decode_llr_kernel(PolarDecodeParams p)
                     pL.set(sh, lig);
                 }
                 wave_mem_fence();
+                PROF(S > SL ? (odd ? 1 : 2) : (S >= 4 ? 3 : 4))
             }
 
             // ---------------- leaf: frozen / unfrozen ----------------
@@ -269,7 +347,9 @@ __global__ __launch_bounds__(64) void scl_decode_llr_kernel(PolarDecodeParams p)
             unsigned ubit = 0;
             if (frozen) {
                 // continuePaths_FrozenBit: PolarCode.cpp:475-487
-                if (active) pm += softplus_ref(-leaf, tb);
+                if (!__all(!active || leaf >= 37.0)) {
+                    if (active) pm += softplus_ref(-leaf, tb);
+                }
             } else {
                 // continuePaths_UnfrozenBit: PolarCode.cpp:489-607
                 const u64 actm = (__ballot(active) >> gbase) & gmask;
@@ -285,13 +365,8 @@ __global__ __launch_bounds__(64) void scl_decode_llr_kernel(PolarDecodeParams p)
                     gm = pm + softplus_ref(-al, tb);
                     bl = (pm + al) * 0.99999999999909050530;
                 }
-                double gmax = gm, bmin = bl;
-#pragma unroll
-                for (int off = GS / 2; off >= 1; off >>= 1) {
-                    double og = shfl_d(gmax, lane ^ off), ob = shfl_d(bmin, lane ^ off);
-                    gmax = (og > gmax) ? og : gmax;
-                    bmin = (ob < bmin) ? ob : bmin;
-                }
+                const double gmax = group_reduce<GS, true>(gm, lane);
+                const double bmin = group_reduce<GS, false>(bl, lane);
                 const bool fastok = (nact == 0) || (nact == L && gmax < bmin);
                 if (__all(fastok)) {
                     if (active) {
@@ -388,6 +463,7 @@ __global__ __launch_bounds__(64) void scl_decode_llr_kernel(PolarDecodeParams p)
                 ++t;
             }
 
+            PROF(frozen ? 5 : 6)
             // ---------------- partial sums ----------------
             if ((phi & 1) == 0) {
                 // left leaf: column 0 of C_n (size 1) lives at bit 1 of clsmall
@@ -436,7 +512,9 @@ __global__ __launch_bounds__(64) void scl_decode_llr_kernel(PolarDecodeParams p)
                     ph = psi;
                 }
             }
+            PROF(7)
         }  // phi
+        PROF_OUT
 
         // ---------------- final flush of the decision history ----------------
         {
@@ -481,7 +559,9 @@ __global__ __launch_bounds__(64) void scl_decode_llr_kernel(PolarDecodeParams p)
         const int win = (key < __builtin_inf()) ? kidx : 0;
         const double pm_win = shfl_d(pm, gbase + win);
         if (valid) {
+#ifndef POLAR_PROFILE
             if (p.pm_out && lig == 0) p.pm_out[cw] = pm_win;
+#endif
             for (int b = lig; b < K; b += GS) {
                 unsigned r = p.info_rank[b];
                 uint32_t wd = g_hist[(size_t)(r >> 5) * 64 + gbase + win];

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Per-phase cycle breakdown of scl_decode_llr_kernel (instrumented build, -DPOLAR_PROFILE).
+Run on the GPU box: python tools/phase_profile.py [L] [batch] [wpc] [lds_log]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from polar_amd import build
+lib = build.build(profile=True)
+import polar_amd
+polar_amd.LIB_PATH = lib
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+wpc = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+ll = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+C.CDLL(None).srand(1)
+g = polar_amd.PolarCode(11, 1024, 0.32, 16)
+g.set_tuning(wpc, ll)
+llr = torch.empty((B, 2048), dtype=torch.float64, device="cuda")
+out = torch.empty((B, 1024), dtype=torch.uint8, device="cuda")
+prof = torch.zeros(max(B, 8), dtype=torch.int64, device="cuda")
+g.synth_llr_dev(1, 0, B, g.snr_sqrt_linear(2.0), llr.data_ptr())
+g.decode_scl_llr_dev(llr.data_ptr(), B, L, out.data_ptr(), prof.data_ptr())
+torch.cuda.synchronize()
+prof.zero_()
+torch.cuda.synchronize()
+import time
+t = time.perf_counter()
+g.decode_scl_llr_dev(llr.data_ptr(), B, L, out.data_ptr(), prof.data_ptr())
+torch.cuda.synchronize()
+dt = time.perf_counter() - t
+a = prof[:8].cpu().numpy().astype(float)
+names = ["loop ovh", "layer S>SL g (HBM)", "layer S>SL f (HBM)", "layer 4<=S<=SL (LDS)", "layer S<4", "leaf frozen", "leaf unfrozen", "partial sums"]
+print(f"L={L} B={B} time {dt*1e3:.2f} ms -> {B/dt:.0f} cw/s")
+for nm, v in zip(names, a):
+    print(f"  {nm:24s} {100*v/a.sum():5.1f}%")
