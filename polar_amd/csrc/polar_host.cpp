@@ -84,7 +84,7 @@ struct polar_code {
     DevBuf<unsigned long long> d_counter;
     DevBuf<uint64_t> d_sel;
     // tuning
-    int waves_per_cu = 0, lds_log = 0;
+    int waves_per_cu = 0, lds_log = 0, pipe = -1;
 };
 
 namespace {
@@ -310,14 +310,20 @@ int polar_decode_scl_llr_batch_dev(polar_code_t *h, const double *d_llr, long B,
     if (rc) return rc;
     const int gs = pow2ceil(L);
     const int G = 64 / gs;
-    int lds_log = h->lds_log ? h->lds_log : 4;
-    const size_t lds = polar_decode_lds_bytes(lds_log);
-    int wpc = h->waves_per_cu ? h->waves_per_cu : 8;
-    const int max_by_lds = (int)((160 * 1024) / lds);
-    if (wpc > max_by_lds) wpc = max_by_lds;
+    // two tuned variants: "pipe" (8 waves/CU, S<=16 in LDS, register double-buffering) and the
+    // default high-occupancy one (4-wave blocks, S<=8 in LDS, 16 waves/CU)
+    int wpc = h->waves_per_cu ? h->waves_per_cu : 16;
+    const int pipe = (wpc > 8) ? 0 : 1;
+    int lds_log = h->lds_log ? h->lds_log : (pipe ? 4 : 3);
+    const int wpb = polar_decode_waves_per_block(pipe);
+    const size_t lds = polar_decode_lds_bytes(lds_log, pipe);
+    const int max_blocks_by_lds = (int)((160 * 1024) / lds);
+    if (max_blocks_by_lds < 1) return fail(POLAR_E_ARG, "lds_log %d does not fit the LDS", lds_log);
+    if (wpc > max_blocks_by_lds * wpb) wpc = max_blocks_by_lds * wpb;
     long groups = (B + G - 1) / G;
     long maxgrid = (long)h->num_cu * wpc;
     int grid = (int)std::min(groups, maxgrid);
+    grid = ((grid + wpb - 1) / wpb) * wpb;          // whole blocks
     const int SL = 1 << lds_log;
     const size_t big = (h->N > 2 * SL) ? (size_t)(h->N - 2 * SL) : 0;
     const size_t cwords = (h->N >= 128) ? (size_t)(h->N / 32 - 2) : 0;
@@ -329,7 +335,7 @@ int polar_decode_scl_llr_batch_dev(polar_code_t *h, const double *d_llr, long B,
     p.llr = d_llr; p.out = d_out; p.pm_out = d_pm;
     p.frozen = h->d_frozen.p; p.info_rank = h->d_info_rank.p; p.crc_mask = h->d_crc_mask.p; p.tabs = h->d_tabs.p;
     p.llr_scr = h->d_llr_scr.p; p.c_scr = h->d_c_scr.p; p.hist_scr = h->d_hist_scr.p;
-    HIP_TRY(polar_launch_decode_llr(p, gs, lds_log, grid, (hipStream_t)stream));
+    HIP_TRY(polar_launch_decode_llr(p, gs, lds_log, pipe, grid, (hipStream_t)stream));
     return POLAR_OK;
 }
 

@@ -20,8 +20,9 @@ struct PolarDecodeParams {
     uint32_t *hist_scr;          // per-wave scratch: [grid][W][64]
 };
 
-size_t polar_decode_lds_bytes(int lds_log);
-hipError_t polar_launch_decode_llr(const PolarDecodeParams &p, int gs, int lds_log, int grid, hipStream_t st);
+size_t polar_decode_lds_bytes(int lds_log, int pipe);
+int polar_decode_waves_per_block(int pipe);
+hipError_t polar_launch_decode_llr(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, hipStream_t st);
 
 struct PolarEncodeParams {
     int n, N, K, crc;

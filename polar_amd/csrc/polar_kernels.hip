@@ -171,11 +171,17 @@ __device__ __forceinline__ void wave_mem_fence() {
 //
 // GS  : lanes per codeword (power of two >= L)
 // LDS_LOG : log2 of the largest layer size kept in LDS
-template <int GS, int LDS_LOG>
-__global__ __launch_bounds__(64) void scl_decode_llr_kernel(PolarDecodeParams p) {
+template <int GS, int LDS_LOG, int PIPE>
+__global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : 4) void scl_decode_llr_kernel(PolarDecodeParams p) {
+    // PIPE=1: one wave per block (8 waves/CU, register double-buffering); PIPE=0: four independent
+    // waves per block sharing the transcendental tables (16 waves/CU with LDS_LOG = 3)
+    constexpr int WPB = PIPE ? 1 : 4;
     constexpr int G = 64 / GS;
     constexpr int SL = 1 << LDS_LOG;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;                       // wave in block
+    const int wave_id = blockIdx.x * WPB + wib;             // owns one slice of the global scratch
+    const int nwaves = gridDim.x * WPB;
     const int lig = lane & (GS - 1);   // path index l of the reference
     const int gbase = lane & ~(GS - 1);
     const int grp = lane / GS;
@@ -184,23 +190,26 @@ __global__ __launch_bounds__(64) void scl_decode_llr_kernel(PolarDecodeParams p)
     const u64 below = (1ull << lig) - 1ull;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *lds_llr = reinterpret_cast<double *>(smem);                        // [(2*SL-1)][64]
+    double *tabs = reinterpret_cast<double *>(smem);                           // T[64] RC[129] LC[129] (+2 pad), per block
+    constexpr size_t WAVE_LDS = (size_t)(2 * SL - 1) * 64 * 8 + 128 * 8 + 128;  // bytes per wave
+    unsigned char *wbase = smem + 324 * 8 + (size_t)wib * WAVE_LDS;
+    double *lds_llr = reinterpret_cast<double *>(wbase);                       // [(2*SL-1)][64]
     double *sortbuf = lds_llr + (size_t)(2 * SL - 1) * 64;                     // [128]
-    double *tabs = sortbuf + 128;                                              // T[64] RC[129] LC[129] (+2 pad)
-    volatile unsigned char *stackv = reinterpret_cast<unsigned char *>(tabs + 324);      // [64]
+    volatile unsigned char *stackv = reinterpret_cast<unsigned char *>(sortbuf + 128);   // [64]
     volatile unsigned char *srcof = stackv + 64;                               // [64]
-    for (int i = lane; i < 322; i += 64) tabs[i] = p.tabs[i];
+    for (int i = threadIdx.x; i < 322; i += WPB * 64) tabs[i] = p.tabs[i];
+    if (WPB > 1) __syncthreads();
     const Tabs tb = {tabs, tabs + 64, tabs + 64 + 129};
 
     // per-wave global scratch
     const size_t big_elems = (N > 2 * SL) ? (size_t)(N - 2 * SL) : 0;
-    double *g_llr = p.llr_scr + (size_t)blockIdx.x * big_elems * 64;
+    double *g_llr = p.llr_scr + (size_t)wave_id * big_elems * 64;
     const int cwords = (N >= 128) ? (N / 32 - 2) : 0;                          // words of big C layers (S >= 64)
-    uint32_t *g_cl = p.c_scr + (size_t)blockIdx.x * 2 * (size_t)cwords * 64;
+    uint32_t *g_cl = p.c_scr + (size_t)wave_id * 2 * (size_t)cwords * 64;
     uint32_t *g_cr = g_cl + (size_t)cwords * 64;
-    uint32_t *g_hist = p.hist_scr + (size_t)blockIdx.x * (size_t)p.W * 64;
+    uint32_t *g_hist = p.hist_scr + (size_t)wave_id * (size_t)p.W * 64;
 
-    for (long g0 = (long)blockIdx.x * G; g0 < p.B; g0 += (long)gridDim.x * G) {
+    for (long g0 = (long)wave_id * G; g0 < p.B; g0 += (long)nwaves * G) {
         const long cw = g0 + grp;
         const bool valid = (cw < p.B);
         const double *in0 = p.llr + (size_t)(valid ? cw : 0) * N;
@@ -250,7 +259,7 @@ __global__ __launch_bounds__(64) void scl_decode_llr_kernel(PolarDecodeParams p)
                         if (S <= 32) cbits = (uint32_t)(clsmall >> S);
                         else cwp = g_cl + (size_t)(S / 32 - 2) * 64 + gbase + pC.get(sh);
                     }
-                    if (S >= 16 && !in_lds) {
+                    if (PIPE && S >= 16 && !in_lds) {
                         // source in HBM/L2 (channel LLRs or a scratch layer): software-pipelined,
                         // 8 elements (16 loads, 8 KiB per wave) in flight ahead of the compute
                         constexpr int U = 8;
@@ -573,29 +582,39 @@ __global__ __launch_bounds__(64) void scl_decode_llr_kernel(PolarDecodeParams p)
 }
 
 // ------------------------------------------------------------------------------------------
-size_t polar_decode_lds_bytes(int lds_log) { return (size_t)((2u << lds_log) - 1) * 64 * 8 + 128 * 8 + 324 * 8 + 128; }
+int polar_decode_waves_per_block(int pipe) { return pipe ? 1 : 4; }
+size_t polar_decode_lds_bytes(int lds_log, int pipe) {
+    return 324 * 8 + (size_t)polar_decode_waves_per_block(pipe) * ((size_t)((2u << lds_log) - 1) * 64 * 8 + 128 * 8 + 128);
+}
 
 template <int GS>
-static hipError_t launch_gs(const PolarDecodeParams &p, int lds_log, int grid, hipStream_t st) {
-    size_t lds = polar_decode_lds_bytes(lds_log);
-    switch (lds_log) {
-        case 3: hipLaunchKernelGGL((scl_decode_llr_kernel<GS, 3>), dim3(grid), dim3(64), lds, st, p); break;
-        case 4: hipLaunchKernelGGL((scl_decode_llr_kernel<GS, 4>), dim3(grid), dim3(64), lds, st, p); break;
-        case 5: hipLaunchKernelGGL((scl_decode_llr_kernel<GS, 5>), dim3(grid), dim3(64), lds, st, p); break;
+static hipError_t launch_gs(const PolarDecodeParams &p, int lds_log, int pipe, int grid, hipStream_t st) {
+    // `grid` counts WAVES; blocks = grid / waves-per-block (the host rounds grid to a multiple)
+    size_t lds = polar_decode_lds_bytes(lds_log, pipe);
+    const int wpb = polar_decode_waves_per_block(pipe);
+#define POLAR_LAUNCH(LL, PP) hipLaunchKernelGGL((scl_decode_llr_kernel<GS, LL, PP>), dim3(grid / wpb), dim3(64 * wpb), lds, st, p)
+    switch (lds_log * 2 + (pipe ? 1 : 0)) {
+        case 6: POLAR_LAUNCH(3, 0); break;
+        case 7: POLAR_LAUNCH(3, 1); break;
+        case 8: POLAR_LAUNCH(4, 0); break;
+        case 9: POLAR_LAUNCH(4, 1); break;
+        case 10: POLAR_LAUNCH(5, 0); break;
+        case 11: POLAR_LAUNCH(5, 1); break;
         default: return hipErrorInvalidValue;
     }
+#undef POLAR_LAUNCH
     return hipGetLastError();
 }
 
-hipError_t polar_launch_decode_llr(const PolarDecodeParams &p, int gs, int lds_log, int grid, hipStream_t st) {
+hipError_t polar_launch_decode_llr(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, hipStream_t st) {
     switch (gs) {
-        case 1: return launch_gs<1>(p, lds_log, grid, st);
-        case 2: return launch_gs<2>(p, lds_log, grid, st);
-        case 4: return launch_gs<4>(p, lds_log, grid, st);
-        case 8: return launch_gs<8>(p, lds_log, grid, st);
-        case 16: return launch_gs<16>(p, lds_log, grid, st);
-        case 32: return launch_gs<32>(p, lds_log, grid, st);
-        case 64: return launch_gs<64>(p, lds_log, grid, st);
+        case 1: return launch_gs<1>(p, lds_log, pipe, grid, st);
+        case 2: return launch_gs<2>(p, lds_log, pipe, grid, st);
+        case 4: return launch_gs<4>(p, lds_log, pipe, grid, st);
+        case 8: return launch_gs<8>(p, lds_log, pipe, grid, st);
+        case 16: return launch_gs<16>(p, lds_log, pipe, grid, st);
+        case 32: return launch_gs<32>(p, lds_log, pipe, grid, st);
+        case 64: return launch_gs<64>(p, lds_log, pipe, grid, st);
         default: return hipErrorInvalidValue;
     }
 }
