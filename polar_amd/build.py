@@ -80,5 +80,19 @@ def build(force=False, verbose=False, profile=False):
     return lib_out
 
 
+def build_cli(force=False):
+    """C++ driver mirroring the reference's main.cpp over the header-only class mirror
+    (polar_amd/cpp/PolarCode.hpp -> C-ABI)."""
+    lib = build()
+    exe = os.path.join(BUILD, "polar_main")
+    src = os.path.join(HERE, "cpp", "main.cpp")
+    hdr = os.path.join(HERE, "cpp", "PolarCode.hpp")
+    if force or _newer(exe, [src, hdr, lib]):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", INC, "-I", os.path.join(HERE, "cpp"), src, "-o", exe,
+                               "-L", HERE, "-lpolar_amd", "-Wl,-rpath," + HERE,
+                               "-Wl,-rpath," + (_torch_lib() or "/opt/rocm/lib"), "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True, profile="--profile" in sys.argv))

@@ -1,0 +1,83 @@
+// polar_mex.cpp — MEX gateway: command string + uint64 handle -> C-ABI (include/polar_amd.h).
+// Build (needs MATLAB, not available in the build image — source delivered):
+//   mex -I<repo>/include polar_mex.cpp -L<repo>/polar_amd -lpolar_amd
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mex.h"
+#include "polar_amd.h"
+
+static void check(int rc) {
+    if (rc != POLAR_OK) mexErrMsgIdAndTxt("polar_amd:error", "%s", polar_last_error());
+}
+static polar_code_t *H(const mxArray *a) { return (polar_code_t *)(uintptr_t)(*(uint64_t *)mxGetData(a)); }
+
+void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
+    if (nrhs < 1 || !mxIsChar(prhs[0])) mexErrMsgIdAndTxt("polar_amd:usage", "polar_mex(cmd, ...)");
+    char cmd[64];
+    mxGetString(prhs[0], cmd, sizeof cmd);
+    std::string c(cmd);
+    if (c == "create") {
+        polar_code_t *h = nullptr;
+        check(polar_create((int)mxGetScalar(prhs[1]), (int)mxGetScalar(prhs[2]), mxGetScalar(prhs[3]),
+                           (int)mxGetScalar(prhs[4]), &h));
+        mexLock();
+        plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
+        *(uint64_t *)mxGetData(plhs[0]) = (uint64_t)(uintptr_t)h;
+        return;
+    }
+    polar_code_t *h = H(prhs[1]);
+    int n, N, K, crc;
+    check(polar_get_params(h, &n, &N, &K, &crc));
+    if (c == "destroy") {
+        polar_destroy(h);
+        mexUnlock();
+    } else if (c == "tables") {
+        plhs[0] = mxCreateNumericMatrix(1, N, mxUINT8_CLASS, mxREAL);
+        check(polar_get_frozen(h, (uint8_t *)mxGetData(plhs[0])));
+        plhs[1] = mxCreateNumericMatrix(1, N, mxUINT16_CLASS, mxREAL);
+        check(polar_get_order(h, (uint16_t *)mxGetData(plhs[1])));
+        std::vector<uint8_t> m((size_t)crc * K);
+        check(polar_get_crc_matrix(h, m.data()));
+        plhs[2] = mxCreateNumericMatrix(crc, K, mxUINT8_CLASS, mxREAL);   // column-major
+        uint8_t *d = (uint8_t *)mxGetData(plhs[2]);
+        for (int i = 0; i < crc; ++i)
+            for (int j = 0; j < K; ++j) d[(size_t)j * crc + i] = m[(size_t)i * K + j];
+    } else if (c == "encode") {
+        plhs[0] = mxCreateNumericMatrix(1, N, mxUINT8_CLASS, mxREAL);
+        check(polar_encode(h, (const uint8_t *)mxGetData(prhs[2]), (uint8_t *)mxGetData(plhs[0])));
+    } else if (c == "decode_scl_llr") {
+        // B x N column-major from MATLAB -> row-major batch
+        size_t B = mxGetM(prhs[2]), cols = mxGetN(prhs[2]);
+        if (cols != (size_t)N) { if (B * cols == (size_t)N) { B = 1; } else mexErrMsgIdAndTxt("polar_amd:size", "llr must be B x N"); }
+        const double *x = mxGetPr(prhs[2]);
+        std::vector<double> llr(B * N);
+        if (B == 1) memcpy(llr.data(), x, sizeof(double) * N);
+        else for (size_t b = 0; b < B; ++b) for (int i = 0; i < N; ++i) llr[b * N + i] = x[(size_t)i * B + b];
+        std::vector<uint8_t> out(B * K);
+        check(polar_decode_scl_llr_batch(h, llr.data(), (long)B, (int)mxGetScalar(prhs[3]), out.data()));
+        plhs[0] = mxCreateNumericMatrix(B, K, mxUINT8_CLASS, mxREAL);
+        uint8_t *d = (uint8_t *)mxGetData(plhs[0]);
+        for (size_t b = 0; b < B; ++b) for (int i = 0; i < K; ++i) d[(size_t)i * B + b] = out[b * K + i];
+    } else if (c == "decode_scl_p1") {
+        plhs[0] = mxCreateNumericMatrix(1, K, mxUINT8_CLASS, mxREAL);
+        check(polar_decode_scl_p1(h, mxGetPr(prhs[2]), mxGetPr(prhs[3]), (int)mxGetScalar(prhs[4]),
+                                  (uint8_t *)mxGetData(plhs[0])));
+    } else if (c == "decode_sc_p1") {
+        plhs[0] = mxCreateNumericMatrix(1, K, mxUINT8_CLASS, mxREAL);
+        check(polar_decode_sc_p1(h, mxGetPr(prhs[2]), (uint8_t *)mxGetData(plhs[0])));
+    } else if (c == "get_bler_quick") {
+        int n_e = (int)mxGetNumberOfElements(prhs[2]), n_L = (int)mxGetNumberOfElements(prhs[3]);
+        long max_runs = (long)mxGetScalar(prhs[4]), max_err = (long)mxGetScalar(prhs[5]);
+        uint64_t seed = (uint64_t)mxGetScalar(prhs[6]);
+        std::vector<double> b((size_t)n_e * n_L);
+        check(polar_get_bler_quick(h, mxGetPr(prhs[2]), n_e, (const uint8_t *)mxGetData(prhs[3]), n_L, max_runs,
+                                   max_err, seed, max_runs, b.data()));
+        plhs[0] = mxCreateDoubleMatrix(n_L, n_e, mxREAL);
+        double *d = mxGetPr(plhs[0]);
+        for (int l = 0; l < n_L; ++l) for (int e = 0; e < n_e; ++e) d[(size_t)e * n_L + l] = b[(size_t)l * n_e + e];
+    } else {
+        mexErrMsgIdAndTxt("polar_amd:cmd", "unknown command %s", cmd);
+    }
+}
