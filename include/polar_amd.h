@@ -89,9 +89,11 @@ int polar_decode_scl_llr_batch_dev(polar_code_t *h, const double *d_llr, long B,
 int polar_decode_scl_p1(polar_code_t *h, const double *p1 /*[N]*/, const double *p0 /*[N]*/, int L, uint8_t *out /*[K]*/);
 int polar_decode_scl_p1_batch(polar_code_t *h, const double *p1, const double *p0, long B, int L, uint8_t *out);
 
-/* ---- PolarM decode_sc_p1 (PolarCode.m:290-295, 870-895): SC on p1 = P(bit = 1) ---- */
-int polar_decode_sc_p1(polar_code_t *h, const double *p1 /*[N]*/, uint8_t *out /*[K]*/);
-int polar_decode_sc_p1_batch(polar_code_t *h, const double *p1, long B, uint8_t *out);
+/* ---- PolarM decode_sc_p1 (PolarCode.m:290-295, 870-895): SC on p1 = P(bit = 1) ----
+ * out are doubles, as MATLAB returns them: 0 / 1, and 0.5 where a leaf probability is exactly 0.5
+ * (sign(0) = 0 at PolarCode.m:873). */
+int polar_decode_sc_p1(polar_code_t *h, const double *p1 /*[N]*/, double *out /*[K]*/);
+int polar_decode_sc_p1_batch(polar_code_t *h, const double *p1, long B, double *out);
 
 /* ---- synthetic BPSK/AWGN workload (include/polar_synth.h), generated on the device ----
  * trials [trial0, trial0+B): info bits (block = trial/100), encode, BPSK, AWGN, LLR with

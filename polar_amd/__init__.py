@@ -200,8 +200,8 @@ class PolarCode:
         a = np.ascontiguousarray(p1, np.float64)
         single = a.ndim == 1
         a2 = a.reshape(-1, self.N)
-        out = np.zeros((a2.shape[0], self.K), np.uint8)
-        _check(lib().polar_decode_sc_p1_batch(self._h, _p(a2, _dp), C.c_long(a2.shape[0]), _p(out, _u8p)))
+        out = np.zeros((a2.shape[0], self.K), np.float64)
+        _check(lib().polar_decode_sc_p1_batch(self._h, _p(a2, _dp), C.c_long(a2.shape[0]), _p(out, _dp)))
         return out[0] if single else out
 
     # names used by BASELINE.json's north_star

@@ -54,9 +54,9 @@ public:
         return out;
     }
     // PolarM's SC decoder (PolarCode.m:290)
-    std::vector<uint8_t> decode_sc_p1(std::vector<double> p1) {
+    std::vector<double> decode_sc_p1(std::vector<double> p1) {
         need(p1.size() == _block_length, "decode_sc_p1: need block_length values");
-        std::vector<uint8_t> out(_info_length);
+        std::vector<double> out(_info_length);
         check(polar_decode_sc_p1(_h, p1.data(), out.data()));
         return out;
     }

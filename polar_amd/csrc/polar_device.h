@@ -1,0 +1,56 @@
+// polar_device.h — device-side helpers shared by the decode kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+
+typedef unsigned long long u64;
+
+// 16 one-byte slot pointers packed in two 64-bit registers, indexed by a wave-uniform i
+struct P16 {
+    u64 lo, hi;
+    __device__ __forceinline__ int get(int i) const {
+        return i < 8 ? (int)((lo >> (8 * i)) & 0xFFull) : (int)((hi >> (8 * (i - 8))) & 0xFFull);
+    }
+    __device__ __forceinline__ void set(int i, int v) {
+        if (i < 8) lo = (lo & ~(0xFFull << (8 * i))) | ((u64)(unsigned)v << (8 * i));
+        else hi = (hi & ~(0xFFull << (8 * (i - 8)))) | ((u64)(unsigned)v << (8 * (i - 8)));
+    }
+};
+
+__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl(lo, src, 64);
+    hi = __shfl(hi, src, 64);
+    return ((u64)hi << 32) | lo;
+}
+// cross-lane max/min over the GS lanes of a group: DPP inside a row of 16 (quad xor1, xor2,
+// half-mirror, mirror), ds_bpermute across rows
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int GS, bool MAX>
+__device__ __forceinline__ double group_reduce(double v, int lane) {
+    auto op = [](double a, double b) { return MAX ? ((b > a) ? b : a) : ((b < a) ? b : a); };
+    if (GS >= 2) v = op(v, dpp_d<0xB1>(v));      // quad_perm [1,0,3,2]
+    if (GS >= 4) v = op(v, dpp_d<0x4E>(v));      // quad_perm [2,3,0,1]
+    if (GS >= 8) v = op(v, dpp_d<0x141>(v));     // row_half_mirror
+    if (GS >= 16) v = op(v, dpp_d<0x140>(v));    // row_mirror
+    if (GS >= 32) v = op(v, __shfl(v, lane ^ 16, 64));
+    if (GS >= 64) v = op(v, __shfl(v, lane ^ 32, 64));
+    return v;
+}
+__device__ __forceinline__ void wave_mem_fence() {
+    // lanes of one wave exchange data through LDS/global: keep the compiler from caching or
+    // reordering across this point (hardware executes a wave's memory ops in order)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+}  // namespace

@@ -332,7 +332,7 @@ int polar_decode_scl_llr_batch_dev(polar_code_t *h, const double *d_llr, long B,
     if ((rc = h->d_hist_scr.ensure((size_t)grid * h->W * 64 + 64))) return rc;
     PolarDecodeParams p;
     p.n = h->n; p.N = h->N; p.K = h->K; p.crc = h->crc; p.L = L; p.W = h->W; p.B = B;
-    p.llr = d_llr; p.out = d_out; p.pm_out = d_pm;
+    p.llr = d_llr; p.p0 = nullptr; p.out = d_out; p.pm_out = d_pm;
     p.frozen = h->d_frozen.p; p.info_rank = h->d_info_rank.p; p.crc_mask = h->d_crc_mask.p; p.tabs = h->d_tabs.p;
     p.llr_scr = h->d_llr_scr.p; p.c_scr = h->d_c_scr.p; p.hist_scr = h->d_hist_scr.p;
     HIP_TRY(polar_launch_decode_llr(p, gs, lds_log, pipe, grid, (hipStream_t)stream));
@@ -359,18 +359,62 @@ int polar_decode_scl_llr(polar_code_t *h, const double *llr, int L, uint8_t *out
     return polar_decode_scl_llr_batch(h, llr, 1, L, out);
 }
 
-int polar_decode_scl_p1(polar_code_t *, const double *, const double *, int, uint8_t *) {
-    return fail(POLAR_E_UNSUPPORTED, "decode_scl_p1: probability-domain SCL is not implemented yet (SURVEY 8f N3)");
+// PolarCode::decode_scl_p1 (PolarCode.cpp:110-128): probability-domain SCL
+int polar_decode_scl_p1_batch(polar_code_t *h, const double *p1, const double *p0, long B, int L, uint8_t *out) {
+    if (!h || !p1 || !p0 || !out) return fail(POLAR_E_ARG, "NULL argument");
+    if (L < 1 || L > POLAR_MAX_LIST) return fail(POLAR_E_ARG, "list size %d out of range [1, %d]", L, POLAR_MAX_LIST);
+    if (B < 0) return fail(POLAR_E_ARG, "negative batch");
+    if (B == 0) return POLAR_OK;
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    const int N = h->N;
+    const int gs = pow2ceil(L), G = 64 / gs;
+    long groups = (B + G - 1) / G;
+    int grid = (int)std::min<long>(groups, (long)h->num_cu * 4);
+    const size_t cwords = (N >= 128) ? (size_t)(N / 32 - 2) : 0;
+    if ((rc = h->d_in.ensure((size_t)B * N * 2))) return rc;
+    if ((rc = h->d_out.ensure((size_t)B * h->K))) return rc;
+    if ((rc = h->d_llr_scr.ensure((size_t)grid * N * 64 * 2 + 64))) return rc;
+    if ((rc = h->d_c_scr.ensure((size_t)grid * 2 * cwords * 64 + 64))) return rc;
+    if ((rc = h->d_hist_scr.ensure((size_t)grid * h->W * 64 + 64))) return rc;
+    HIP_TRY(hipMemcpy(h->d_in.p, p1, (size_t)B * N * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_in.p + (size_t)B * N, p0, (size_t)B * N * sizeof(double), hipMemcpyHostToDevice));
+    PolarDecodeParams p;
+    p.n = h->n; p.N = N; p.K = h->K; p.crc = h->crc; p.L = L; p.W = h->W; p.B = B;
+    p.llr = h->d_in.p; p.p0 = h->d_in.p + (size_t)B * N; p.out = h->d_out.p; p.pm_out = nullptr;
+    p.frozen = h->d_frozen.p; p.info_rank = h->d_info_rank.p; p.crc_mask = h->d_crc_mask.p; p.tabs = h->d_tabs.p;
+    p.llr_scr = h->d_llr_scr.p; p.c_scr = h->d_c_scr.p; p.hist_scr = h->d_hist_scr.p;
+    HIP_TRY(polar_launch_decode_p1(p, gs, grid, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, h->d_out.p, (size_t)B * h->K, hipMemcpyDeviceToHost));
+    return POLAR_OK;
 }
-int polar_decode_scl_p1_batch(polar_code_t *, const double *, const double *, long, int, uint8_t *) {
-    return fail(POLAR_E_UNSUPPORTED, "decode_scl_p1: probability-domain SCL is not implemented yet (SURVEY 8f N3)");
+int polar_decode_scl_p1(polar_code_t *h, const double *p1, const double *p0, int L, uint8_t *out) {
+    return polar_decode_scl_p1_batch(h, p1, p0, 1, L, out);
 }
-int polar_decode_sc_p1(polar_code_t *, const double *, uint8_t *) {
-    return fail(POLAR_E_UNSUPPORTED, "decode_sc_p1 is not implemented yet");
+
+// PolarM decode_sc_p1 (PolarCode.m:290-295): out are doubles like MATLAB's (0.5 when a leaf is exactly 0.5)
+int polar_decode_sc_p1_batch(polar_code_t *h, const double *p1, long B, double *out) {
+    if (!h || !p1 || !out) return fail(POLAR_E_ARG, "NULL argument");
+    if (B < 0) return fail(POLAR_E_ARG, "negative batch");
+    if (B == 0) return POLAR_OK;
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    const int N = h->N;
+    int grid = (int)std::min<long>((B + 63) / 64, (long)h->num_cu * 4);
+    if ((rc = h->d_in.ensure((size_t)B * N + (size_t)B * h->K))) return rc;
+    if ((rc = h->d_llr_scr.ensure((size_t)grid * 4 * N * 64 + 64))) return rc;
+    HIP_TRY(hipMemcpy(h->d_in.p, p1, (size_t)B * N * sizeof(double), hipMemcpyHostToDevice));
+    PolarScP1Params p;
+    p.n = h->n; p.N = N; p.K = h->K; p.B = B;
+    p.p1 = h->d_in.p; p.out = h->d_in.p + (size_t)B * N;
+    p.frozen = h->d_frozen.p; p.order = h->d_order.p; p.scr = h->d_llr_scr.p;
+    HIP_TRY(polar_launch_sc_p1(p, grid, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, p.out, (size_t)B * h->K * sizeof(double), hipMemcpyDeviceToHost));
+    return POLAR_OK;
 }
-int polar_decode_sc_p1_batch(polar_code_t *, const double *, long, uint8_t *) {
-    return fail(POLAR_E_UNSUPPORTED, "decode_sc_p1 is not implemented yet");
-}
+int polar_decode_sc_p1(polar_code_t *h, const double *p1, double *out) { return polar_decode_sc_p1_batch(h, p1, 1, out); }
 
 // ------------------------------------------------------------------------------------------
 static void fill_enc(const polar_code *h, PolarEncodeParams &p) {

@@ -8,7 +8,8 @@ struct PolarDecodeParams {
     int n, N, K, crc, L;
     int W;                       // 32-bit words of decision history = ceil((K+crc)/32)
     long B;                      // codewords
-    const double *llr;           // [B][N] device
+    const double *llr;           // [B][N] device (LLR mode: llr; probability mode: p1)
+    const double *p0;            // [B][N] device (probability mode only)
     uint8_t *out;                // [B][K] device
     double *pm_out;              // [B] device or nullptr
     const uint8_t *frozen;       // [N] device
@@ -23,6 +24,19 @@ struct PolarDecodeParams {
 size_t polar_decode_lds_bytes(int lds_log, int pipe);
 int polar_decode_waves_per_block(int pipe);
 hipError_t polar_launch_decode_llr(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, hipStream_t st);
+
+hipError_t polar_launch_decode_p1(const PolarDecodeParams &p, int gs, int grid, hipStream_t st);
+
+struct PolarScP1Params {
+    int n, N, K;
+    long B;
+    const double *p1;            // [B][N] device
+    double *out;                 // [B][K] device (doubles, as MATLAB: 0.5 possible)
+    const uint8_t *frozen;       // [N]
+    const uint16_t *order;       // [N]
+    double *scr;                 // per-wave scratch [grid][4*N][64]
+};
+hipError_t polar_launch_sc_p1(const PolarScP1Params &p, int grid, hipStream_t st);
 
 struct PolarEncodeParams {
     int n, N, K, crc;

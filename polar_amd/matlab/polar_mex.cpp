@@ -65,8 +65,8 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         check(polar_decode_scl_p1(h, mxGetPr(prhs[2]), mxGetPr(prhs[3]), (int)mxGetScalar(prhs[4]),
                                   (uint8_t *)mxGetData(plhs[0])));
     } else if (c == "decode_sc_p1") {
-        plhs[0] = mxCreateNumericMatrix(1, K, mxUINT8_CLASS, mxREAL);
-        check(polar_decode_sc_p1(h, mxGetPr(prhs[2]), (uint8_t *)mxGetData(plhs[0])));
+        plhs[0] = mxCreateDoubleMatrix(1, K, mxREAL);
+        check(polar_decode_sc_p1(h, mxGetPr(prhs[2]), mxGetPr(plhs[0])));
     } else if (c == "get_bler_quick") {
         int n_e = (int)mxGetNumberOfElements(prhs[2]), n_L = (int)mxGetNumberOfElements(prhs[3]);
         long max_runs = (long)mxGetScalar(prhs[4]), max_err = (long)mxGetScalar(prhs[5]);

@@ -161,3 +161,30 @@ def test_full_size_roundtrip_config4(built_lib):
     g.decode_scl_llr_dev(llr.data_ptr(), B, 32, out.data_ptr())
     torch.cuda.synchronize()
     assert torch.equal(out, info)
+
+
+@pytest.mark.parametrize("n,K,crc", [(5, 16, 4), (8, 128, 0), (10, 512, 8)])
+@pytest.mark.parametrize("L", [1, 4, 8, 32])
+def test_decode_scl_p1_matches_oracle(built_lib, oracle_built, n, K, crc, L):
+    """Probability-domain SCL (PolarCode.cpp:110-128, 375-420) incl. the cross-path normalisation."""
+    o, g = _pair(n, K, crc)
+    llr, _ = o.synth_llr(2222, 0, 24, o.snr_sqrt_linear(2.0))
+    p1 = 1.0 / (1.0 + np.exp(llr))
+    p0 = 1.0 - p1
+    got = g.decode_scl_p1(p1, p0, L)
+    for i in range(llr.shape[0]):
+        assert (got[i] == o.decode_scl_p1(p1[i], p0[i], L)).all(), (i, L)
+
+
+def test_decode_sc_p1_matches_oracle(built_lib, oracle_built):
+    """PolarM decode_sc_p1 (cnop/vnop recursion): bitwise-equal doubles, incl. the y == 0.5 -> 0.5 quirk."""
+    o, g = _pair(9, 256, 0)
+    llr, _ = o.synth_llr(3333, 0, 70, o.snr_sqrt_linear(2.0))
+    p1 = 1.0 / (1.0 + np.exp(llr))
+    p1[3, ::7] = 0.5
+    p1[4, :] = 0.5
+    got = g.decode_sc_p1(p1)
+    for i in range(p1.shape[0]):
+        assert (got[i] == o.decode_sc_p1(p1[i])).all(), i
+    # agrees with the LLR decoder at L = 1 on ordinary inputs (SURVEY 8c cross-check)
+    assert (got[10:] == g.decode_scl_llr(llr[10:], 1)).all()
