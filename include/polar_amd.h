@@ -125,6 +125,17 @@ int polar_mc_batch(polar_code_t *h, uint64_t seed, uint64_t t0, long T, long str
                    const double *ebno, int n_e, const uint8_t *L, int n_L,
                    const uint8_t *enabled /*[n_L*n_e]*/, uint64_t *err, uint64_t *run);
 
+/* ---- ASK Gray + BICM front end (PolarM/Constellation.m:84-93, 123-144; sweep conventions of
+ * PolarM/main_MC_CC_Comparison.m:88-96) for the 16-ASK configuration: `constellation` is
+ * POLAR_CONST_ASK{4,8,16}_GRAY (include/polar_synth.h), the sweep axis is the SNR in dB
+ * (Eb/N0 = snr_db + 10log10(N/K) - 10log10(n_bits), main_MC_CC_Comparison.m:121), info bits are
+ * fresh every run. Same counters/semantics as polar_mc_batch. */
+int polar_synth_bicm_llr_dev(polar_code_t *h, int constellation, uint64_t seed, uint64_t trial0, long B,
+                             double snr_db, double *d_llr, uint8_t *d_info, void *stream);
+int polar_mc_batch_bicm(polar_code_t *h, int constellation, uint64_t seed, uint64_t t0, long T, long stride,
+                        const double *snr_db, int n_s, const uint8_t *L, int n_L,
+                        const uint8_t *enabled, uint64_t *err, uint64_t *run);
+
 /* tuning knobs (0 = default): waves resident per CU and LDS-resident layer exponent */
 int polar_set_tuning(polar_code_t *h, int waves_per_cu, int lds_log);
 

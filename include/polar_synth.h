@@ -165,4 +165,95 @@ POLAR_SYNTH_FN double polar_synth_llr(double s, int coded_bit, double z) {
     return (-4.0 * y) * s;
 }
 
+/* ===================== ASK Gray / BICM front end (PolarM/Constellation.m) =====================
+ * Constellation tables :19-32, unit-energy normalisation :80, symbol index = sum 2^(j-1) bit_j
+ * (LSB first) :86-91, bit_sym_map(sym, j) = bit j-1 of sym :71-78, BICM demapper :123-144.
+ * MATLAB cannot run in the build image, so this part is "parity unpinned" by the reference; it is
+ * cross-checked against an independent numpy evaluation (tests/test_bicm.py). exp/log use the
+ * fixed-order routines of this header so that host and device agree bit for bit. */
+#define POLAR_SYNTH_STREAM_SYMNOISE 2u
+#define POLAR_CONST_ASK4_GRAY 1
+#define POLAR_CONST_ASK8_GRAY 2
+#define POLAR_CONST_ASK16_GRAY 3
+
+POLAR_SYNTH_FN int polar_const_nbits(int id) { return id == POLAR_CONST_ASK4_GRAY ? 2 : (id == POLAR_CONST_ASK8_GRAY ? 3 : 4); }
+
+/* un-normalised integer levels (Constellation.m:21,25,29-30) and the sqrt() divisor */
+POLAR_SYNTH_FN double polar_const_point(int id, int sym) {
+    double lvl, div;
+    if (id == POLAR_CONST_ASK4_GRAY) {
+        const int t[4] = {-3, -1, 3, 1};
+        lvl = (double)t[sym & 3]; div = 5.0;
+    } else if (id == POLAR_CONST_ASK8_GRAY) {
+        const int t[8] = {-7, -5, -1, -3, 7, 5, 1, 3};
+        lvl = (double)t[sym & 7]; div = 21.0;
+    } else {
+        const int t[16] = {-15, -13, -9, -11, -1, -3, -7, -5, 15, 13, 9, 11, 1, 3, 7, 5};
+        lvl = (double)t[sym & 15]; div = 85.0;
+    }
+    return lvl / __builtin_sqrt(div);
+}
+/* constellation_points / sqrt(mean(constellation_points.^2)) (:80); mean = sequential sum / n_sym */
+POLAR_SYNTH_FN double polar_const_norm(int id) {
+    const int ns = 1 << polar_const_nbits(id);
+    double acc = 0.0;
+    for (int s = 0; s < ns; ++s) { double x = polar_const_point(id, s); acc = acc + x * x; }
+    return __builtin_sqrt(acc / (double)ns);
+}
+
+/* e^x for x <= 0 (fixed operation order; flushes to 0 below 2^-1022) */
+POLAR_SYNTH_FN double polar_synth_exp_neg(double x) {
+    if (x < -708.0) return 0.0;
+    double t = x * 1.4426950408889634;
+    int k = (int)(t - 0.5);                         /* x <= 0: round to nearest by truncation */
+    double kd = (double)k;
+    double r = (x - kd * 0.693147180369123816490) - kd * 1.90821492927058770002e-10;  /* fdlibm ln2 hi/lo */
+    double p = 1.0 / 6227020800.0;                  /* 1/13! */
+    p = p * r + 1.0 / 479001600.0;
+    p = p * r + 1.0 / 39916800.0;
+    p = p * r + 1.0 / 3628800.0;
+    p = p * r + 1.0 / 362880.0;
+    p = p * r + 1.0 / 40320.0;
+    p = p * r + 1.0 / 5040.0;
+    p = p * r + 1.0 / 720.0;
+    p = p * r + 1.0 / 120.0;
+    p = p * r + 1.0 / 24.0;
+    p = p * r + 1.0 / 6.0;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    union { double d; uint64_t u; } v;
+    v.u = (uint64_t)(1023 + k) << 52;               /* 2^k, k in [-1022, 0] */
+    return p * v.d;
+}
+
+/* one received symbol -> n_bits LLRs, Constellation.m:123-144: p_sym = exp(-|y-x|^2/2/n0),
+ * llr = log(p0/p1) */
+POLAR_SYNTH_FN void polar_synth_bicm_demap(int id, double norm, double y, double n0, double *llr_out) {
+    const int nb = polar_const_nbits(id), ns = 1 << nb;
+    double p0[4] = {0, 0, 0, 0}, p1[4] = {0, 0, 0, 0};
+    for (int s = 0; s < ns; ++s) {
+        double d = y - polar_const_point(id, s) / norm;
+        double ad = d < 0 ? -d : d;
+        double ps = polar_synth_exp_neg(-(ad * ad) / 2 / n0);
+        for (int m = 0; m < nb; ++m) {
+            if (((s >> m) & 1) == 0) p0[m] = p0[m] + ps; else p1[m] = p1[m] + ps;
+        }
+    }
+    for (int m = 0; m < nb; ++m) llr_out[m] = polar_synth_log(p0[m] / p1[m]);
+}
+
+/* N(0,1) variate for symbol `sym` of trial `trial` (one Box-Muller pair per two symbols) */
+POLAR_SYNTH_FN double polar_synth_symbol_noise(uint64_t seed, uint64_t trial, uint32_t sym) {
+    uint32_t r[4];
+    polar_philox4x32(sym >> 1, (uint32_t)trial, (uint32_t)(trial >> 32), POLAR_SYNTH_STREAM_SYMNOISE,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    double u1 = polar_synth_u01(r[0], r[1]);
+    double u2 = polar_synth_u01(r[2], r[3]);
+    double rad = __builtin_sqrt(-2.0 * polar_synth_log(u1));
+    double sn, cs;
+    polar_synth_sincos2pi(u2, &sn, &cs);
+    return (sym & 1) ? rad * sn : rad * cs;
+}
+
 #endif /* POLAR_SYNTH_H */

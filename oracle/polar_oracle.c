@@ -696,6 +696,40 @@ void orc_synth_llr_batch(void *h, uint64_t seed, uint64_t trial0, long B, double
     for (long b = 0; b < B; ++b)
         orc_synth_llr(h, seed, trial0 + (uint64_t)b, s, llr + b * (long)c->N, info_out ? info_out + b * (long)c->K : NULL);
 }
+/* ---------- 16/8/4-ASK Gray BICM front end: Constellation.m:84-93 (modulate), :123-144 (demap),
+ * sweep conventions main_MC_CC_Comparison.m:88-96: sigma = sqrt(1/2)*10^(-snr_db/20), n0 = sigma^2,
+ * y = sym + noise*sigma, fresh info every run (:50). ---------- */
+void orc_synth_bicm_llr(void *h, int cid, uint64_t seed, uint64_t trial, double snr_db, double *llr, uint8_t *info_out) {
+    orc_t *c = (orc_t *)h;
+    const int nb = polar_const_nbits(cid);
+    uint8_t *info = (uint8_t *)malloc((size_t)c->K), *coded = (uint8_t *)malloc((size_t)c->N);
+    for (int w = 0; w * 128 < c->K; ++w) {          /* block = trial: fresh info bits every run */
+        uint32_t r[4];
+        polar_synth_info_word(seed, trial, (uint32_t)w, r);
+        for (int i = 0; i < 128 && w * 128 + i < c->K; ++i) info[w * 128 + i] = (uint8_t)((r[(i >> 5) & 3] >> (i & 31)) & 1u);
+    }
+    orc_encode(h, info, coded);
+    const double norm = polar_const_norm(cid);
+    const double sigma = sqrt(1.0 / 2) * pow(10.0, -snr_db / 20);
+    const double n0 = sigma * sigma;
+    const int nsym = c->N / nb;
+    for (int i = 0; i < c->N; ++i) llr[i] = 0.0;    /* positions beyond nsym*nb: p1 = 0.5 <=> llr = 0 (:94) */
+    for (int i = 0; i < nsym; ++i) {
+        int sym = 0;
+        for (int j = 0; j < nb; ++j) sym += (1 << j) * coded[i * nb + j];
+        double x = polar_const_point(cid, sym) / norm;
+        double y = x + polar_synth_symbol_noise(seed, trial, (uint32_t)i) * sigma;
+        polar_synth_bicm_demap(cid, norm, y, n0, llr + (size_t)i * nb);
+    }
+    if (info_out) memcpy(info_out, info, (size_t)c->K);
+    free(info); free(coded);
+}
+void orc_synth_bicm_llr_batch(void *h, int cid, uint64_t seed, uint64_t trial0, long B, double snr_db, double *llr, uint8_t *info_out) {
+    orc_t *c = (orc_t *)h;
+    for (long b = 0; b < B; ++b)
+        orc_synth_bicm_llr(h, cid, seed, trial0 + (uint64_t)b, snr_db, llr + b * (long)c->N, info_out ? info_out + b * (long)c->K : NULL);
+}
+
 double orc_snr_sqrt_linear(void *h, double ebno_db) {
     orc_t *c = (orc_t *)h;
     return pow(10.0f, ebno_db / 20) * sqrt(((double)c->K) / ((double)c->N));
@@ -707,7 +741,7 @@ double orc_snr_sqrt_linear(void *h, double ebno_db) {
  * Eb/N0 => counted as run, not simulated" hack (:728-742).  Early stop (:725) is evaluated
  * by the CALLER between batches (batch-granular), so this routine takes an `enabled` mask.
  * err/run are uint64 [n_L][n_e] accumulators. */
-void orc_mc_batch(void *h, uint64_t seed, uint64_t t0, long T, long stride, const double *ebno, int n_e,
+static void orc_mc_batch_impl(void *h, int cid, uint64_t seed, uint64_t t0, long T, long stride, const double *ebno, int n_e,
                   const uint8_t *Ls, int n_L, const uint8_t *enabled, uint64_t *err, uint64_t *run) {
     orc_t *c = (orc_t *)h;
     int N = c->N, K = c->K;
@@ -723,8 +757,12 @@ void orc_mc_batch(void *h, uint64_t seed, uint64_t t0, long T, long stride, cons
                 int run_sim = 1;
                 for (int j = 0; j < ie; ++j) if (prev[j]) run_sim = 0;
                 if (!run_sim) continue;
-                double s = orc_snr_sqrt_linear(h, ebno[ie]);
-                orc_synth_llr(h, seed, t0 + (uint64_t)t * (uint64_t)stride, s, llr, info);
+                if (cid == 0) {
+                    double s = orc_snr_sqrt_linear(h, ebno[ie]);
+                    orc_synth_llr(h, seed, t0 + (uint64_t)t * (uint64_t)stride, s, llr, info);
+                } else {
+                    orc_synth_bicm_llr(h, cid, seed, t0 + (uint64_t)t * (uint64_t)stride, ebno[ie], llr, info);
+                }
                 orc_decode_scl_llr(c, llr, Ls[li], dec, NULL);
                 int e = 0;
                 for (int i = 0; i < K; ++i) if (info[i] != dec[i]) { e = 1; break; }
@@ -733,4 +771,13 @@ void orc_mc_batch(void *h, uint64_t seed, uint64_t t0, long T, long stride, cons
         }
     }
     free(llr); free(info); free(dec); free(prev);
+}
+void orc_mc_batch(void *h, uint64_t seed, uint64_t t0, long T, long stride, const double *ebno, int n_e,
+                  const uint8_t *Ls, int n_L, const uint8_t *enabled, uint64_t *err, uint64_t *run) {
+    orc_mc_batch_impl(h, 0, seed, t0, T, stride, ebno, n_e, Ls, n_L, enabled, err, run);
+}
+/* same on the ASK/BICM channel: the sweep axis is the SNR in dB (main_MC_CC_Comparison.m:42,88) */
+void orc_mc_batch_bicm(void *h, int cid, uint64_t seed, uint64_t t0, long T, long stride, const double *snr_db, int n_s,
+                       const uint8_t *Ls, int n_L, const uint8_t *enabled, uint64_t *err, uint64_t *run) {
+    orc_mc_batch_impl(h, cid, seed, t0, T, stride, snr_db, n_s, Ls, n_L, enabled, err, run);
 }

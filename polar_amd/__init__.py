@@ -25,6 +25,9 @@ _u16p = C.POINTER(C.c_uint16)
 _u64p = C.POINTER(C.c_uint64)
 
 
+ASK4_GRAY, ASK8_GRAY, ASK16_GRAY = 1, 2, 3   # include/polar_synth.h POLAR_CONST_*
+
+
 class PolarError(RuntimeError):
     pass
 
@@ -235,6 +238,20 @@ class PolarCode:
         _check(lib().polar_mc_batch(self._h, C.c_uint64(seed), C.c_uint64(t0), C.c_long(T), C.c_long(stride),
                                     _p(ebno, _dp), C.c_int(len(ebno)), _p(Ls, _u8p), C.c_int(len(Ls)),
                                     _p(enabled, _u8p), _p(err, _u64p), _p(run, _u64p)))
+
+    def synth_bicm_llr_dev(self, constellation, seed, trial0, B, snr_db, llr_ptr, info_ptr=0, stream=None):
+        _check(lib().polar_synth_bicm_llr_dev(self._h, C.c_int(constellation), C.c_uint64(seed), C.c_uint64(trial0),
+                                              C.c_long(B), C.c_double(snr_db), C.c_void_p(llr_ptr),
+                                              C.c_void_p(info_ptr), _stream_ptr(stream)))
+
+    def mc_batch_bicm(self, constellation, seed, t0, T, stride, snr_db_vec, list_size_vec, enabled, err, run):
+        snr = np.ascontiguousarray(snr_db_vec, np.float64)
+        Ls = np.ascontiguousarray(list_size_vec, np.uint8)
+        enabled = np.ascontiguousarray(enabled, np.uint8)
+        assert err.dtype == np.uint64 and run.dtype == np.uint64
+        _check(lib().polar_mc_batch_bicm(self._h, C.c_int(constellation), C.c_uint64(seed), C.c_uint64(t0), C.c_long(T),
+                                         C.c_long(stride), _p(snr, _dp), C.c_int(len(snr)), _p(Ls, _u8p),
+                                         C.c_int(len(Ls)), _p(enabled, _u8p), _p(err, _u64p), _p(run, _u64p)))
 
     def get_bler_quick(self, ebno_vec, list_size_vec, max_runs=1000, max_err=100, seed=1, batch=None):
         """PolarCode::get_bler_quick: returns bler[len(list_size_vec)][len(ebno_vec)]."""

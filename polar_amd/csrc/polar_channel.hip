@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64) void synth_kernel(PolarEncodeParams p) {
     const int lane = threadIdx.x;
     for (long b = blockIdx.x; b < p.B; b += gridDim.x) {
         const uint64_t trial = p.sel ? p.sel[b] : (p.trial0 + (uint64_t)b * (uint64_t)p.stride);
-        const uint64_t block = trial / 100;    // info refreshed every 100 runs: PolarCode.cpp:703-707
+        const uint64_t block = trial / (uint64_t)p.info_block_div;   // 100: info refreshed every 100 runs, PolarCode.cpp:703-707
         for (int i = lane; i < p.K; i += 64) {
             uint32_t r[4];
             polar_synth_info_word(p.seed, block, (uint32_t)(i >> 7), r);
@@ -77,6 +77,24 @@ __global__ __launch_bounds__(64) void synth_kernel(PolarEncodeParams p) {
         encode_in_lds(u, inf, p, lane);
         if (p.coded)
             for (int i = lane; i < p.N; i += 64) p.coded[(size_t)b * p.N + i] = u[__brev((unsigned)i) >> (32 - p.n)];
+        if (p.constellation != 0) {
+            // ASK Gray + BICM demapper: Constellation.m:84-93, 123-144 (include/polar_synth.h)
+            const int nb = polar_const_nbits(p.constellation);
+            const int nsym = p.N / nb;
+            double *dl = p.llr + (size_t)b * p.N;
+            for (int i = nsym * nb + lane; i < p.N; i += 64) dl[i] = 0.0;
+            for (int i = lane; i < nsym; i += 64) {
+                int sym = 0;
+                for (int j = 0; j < nb; ++j) sym += (1 << j) * (int)u[__brev((unsigned)(i * nb + j)) >> (32 - p.n)];
+                const double x = polar_const_point(p.constellation, sym) / p.cnorm;
+                const double y = x + polar_synth_symbol_noise(p.seed, trial, (uint32_t)i) * p.sigma;
+                double l4[4];
+                polar_synth_bicm_demap(p.constellation, p.cnorm, y, p.n0, l4);
+                for (int j = 0; j < nb; ++j) dl[(size_t)i * nb + j] = l4[j];
+            }
+            wave_sync();
+            continue;
+        }
         double2 *dst = reinterpret_cast<double2 *>(p.llr + (size_t)b * p.N);
         for (int pr = lane; pr < p.N / 2; pr += 64) {
             double z0, z1;

@@ -19,6 +19,7 @@
 
 #include "polar_amd.h"
 #include "polar_kernels.h"
+#include "polar_synth.h"
 
 namespace {
 
@@ -422,6 +423,7 @@ static void fill_enc(const polar_code *h, PolarEncodeParams &p) {
     p.n = h->n; p.N = h->N; p.K = h->K; p.crc = h->crc;
     p.order = h->d_order.p; p.crcm = h->d_crcm.p;
     p.stride = 1;
+    p.info_block_div = 100;
 }
 
 int polar_encode_batch_dev(polar_code_t *h, const uint8_t *d_info, long B, uint8_t *d_coded, void *stream) {
@@ -475,9 +477,23 @@ int polar_count_errors_dev(polar_code_t *h, const uint8_t *d_a, const uint8_t *d
 }
 
 // ---- Monte-Carlo (PolarCode::get_bler_quick, PolarCode.cpp:658-785) -----------------------
-int polar_mc_batch(polar_code_t *h, uint64_t seed, uint64_t t0, long T, long stride,
-                   const double *ebno, int n_e, const uint8_t *Ls, int n_L,
-                   const uint8_t *enabled, uint64_t *err, uint64_t *run) {
+static void fill_channel(const polar_code *h, PolarEncodeParams &p, int constellation, double snr_point) {
+    p.constellation = constellation;
+    if (constellation == 0) {
+        p.s = polar_snr_sqrt_linear(h, snr_point);           // Eb/N0 in dB, PolarCode.cpp:744-745
+        p.info_block_div = 100;
+    } else {
+        // main_MC_CC_Comparison.m:88-92: sigma = sqrt(1/2) * 10^(-snr_db/20), n0 = sigma^2
+        p.sigma = std::sqrt(1.0 / 2) * std::pow(10.0, -snr_point / 20);
+        p.n0 = p.sigma * p.sigma;
+        p.cnorm = polar_const_norm(constellation);
+        p.info_block_div = 1;                                // fresh info every run (:50)
+    }
+}
+
+static int mc_batch_impl(polar_code_t *h, int constellation, uint64_t seed, uint64_t t0, long T, long stride,
+                         const double *ebno, int n_e, const uint8_t *Ls, int n_L,
+                         const uint8_t *enabled, uint64_t *err, uint64_t *run) {
     if (!h || !ebno || !Ls || !enabled || !err || !run) return fail(POLAR_E_ARG, "NULL argument");
     if (T <= 0 || stride <= 0 || n_e <= 0 || n_L <= 0) return fail(POLAR_E_ARG, "bad sizes");
     for (int i = 0; i < n_L; ++i)
@@ -505,7 +521,8 @@ int polar_mc_batch(polar_code_t *h, uint64_t seed, uint64_t t0, long T, long str
             HIP_TRY(hipMemcpy(h->d_sel.p, alive.data(), (size_t)A * sizeof(uint64_t), hipMemcpyHostToDevice));
             PolarEncodeParams p;
             fill_enc(h, p);
-            p.B = A; p.seed = seed; p.sel = h->d_sel.p; p.s = polar_snr_sqrt_linear(h, ebno[ie]);
+            p.B = A; p.seed = seed; p.sel = h->d_sel.p;
+            fill_channel(h, p, constellation, ebno[ie]);
             p.llr = h->d_in.p; p.info_out = h->d_bytes_a.p;
             HIP_TRY(polar_launch_synth(p, nullptr));
             if ((rc = polar_decode_scl_llr_batch_dev(h, h->d_in.p, A, Ls[li], h->d_out.p, nullptr, nullptr))) return rc;
@@ -517,6 +534,34 @@ int polar_mc_batch(polar_code_t *h, uint64_t seed, uint64_t t0, long T, long str
             alive.swap(next);
         }
     }
+    return POLAR_OK;
+}
+
+int polar_mc_batch(polar_code_t *h, uint64_t seed, uint64_t t0, long T, long stride,
+                   const double *ebno, int n_e, const uint8_t *Ls, int n_L,
+                   const uint8_t *enabled, uint64_t *err, uint64_t *run) {
+    return mc_batch_impl(h, 0, seed, t0, T, stride, ebno, n_e, Ls, n_L, enabled, err, run);
+}
+int polar_mc_batch_bicm(polar_code_t *h, int constellation, uint64_t seed, uint64_t t0, long T, long stride,
+                        const double *snr_db, int n_s, const uint8_t *Ls, int n_L,
+                        const uint8_t *enabled, uint64_t *err, uint64_t *run) {
+    if (constellation < POLAR_CONST_ASK4_GRAY || constellation > POLAR_CONST_ASK16_GRAY)
+        return fail(POLAR_E_ARG, "unknown constellation %d", constellation);
+    return mc_batch_impl(h, constellation, seed, t0, T, stride, snr_db, n_s, Ls, n_L, enabled, err, run);
+}
+int polar_synth_bicm_llr_dev(polar_code_t *h, int constellation, uint64_t seed, uint64_t trial0, long B, double snr_db,
+                             double *d_llr, uint8_t *d_info, void *stream) {
+    if (!h || !d_llr) return fail(POLAR_E_ARG, "NULL argument");
+    if (constellation < POLAR_CONST_ASK4_GRAY || constellation > POLAR_CONST_ASK16_GRAY)
+        return fail(POLAR_E_ARG, "unknown constellation %d", constellation);
+    if (B <= 0) return B == 0 ? POLAR_OK : fail(POLAR_E_ARG, "negative batch");
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    PolarEncodeParams p;
+    fill_enc(h, p);
+    p.B = B; p.seed = seed; p.trial0 = trial0; p.llr = d_llr; p.info_out = d_info;
+    fill_channel(h, p, constellation, snr_db);
+    HIP_TRY(polar_launch_synth(p, (hipStream_t)stream));
     return POLAR_OK;
 }
 

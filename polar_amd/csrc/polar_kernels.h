@@ -50,10 +50,13 @@ struct PolarEncodeParams {
     long stride;                 // trial index = trial0 + b*stride, or sel[b] when sel != nullptr
     const uint64_t *sel;
     double s;
+    int constellation;           // 0 = BPSK (s), else POLAR_CONST_* (sigma, n0, cnorm)
+    double sigma, n0, cnorm;
+    long info_block_div;         // info bits keyed by trial / info_block_div (100 = reference's refresh, 1 = every run)
     double *llr;                 // [B][N]
     uint8_t *info_out;           // [B][K] or nullptr
 };
 hipError_t polar_launch_encode(const PolarEncodeParams &p, hipStream_t st);
-hipError_t polar_launch_synth(const PolarEncodeParams &p, hipStream_t st);
+hipError_t polar_launch_synth(const PolarEncodeParams &p, hipStream_t st);   // BPSK or ASK/BICM by p.constellation
 hipError_t polar_launch_count_errors(const uint8_t *a, const uint8_t *b, long B, int K,
                                      unsigned long long *err, uint8_t *mismatch_flags, hipStream_t st);

@@ -92,6 +92,43 @@ def main():
                 spm.append(sname)
         meta["codes"][name] = {"n": n, "K": K, "crc": crc, "eps": 0.32, "cases": cm, "specials": spm}
 
+    # ---- config 5: N=1024 K=512, Monte-Carlo constructed code for 16-ASK Gray BICM -------------
+    # frozen set / info order from the reference's own data file (PolarCode.m:111-135: load the
+    # error counts, stable ascending sort, first K positions are the info bits), decoded by the
+    # reference's C decoder with those tables; inputs from the ASK/BICM front end of polar_synth.h
+    txt = ("/root/reference/PolarM/CodeConstructionData/MC_block_length_1024_512_cc_method_monte-carlo_"
+           "cc_param_13_ask16-gray_bicm_250000.txt")
+    counts = np.loadtxt(txt)
+    assert counts.shape == (1024,)
+    order5 = np.argsort(counts, kind="stable").astype(np.uint16)        # MATLAB sort is stable
+    assert counts[order5[511]] < counts[order5[512]]                    # no tie at the K boundary (702 vs 728)
+    frozen5 = np.ones(1024, np.uint8)
+    frozen5[order5[:512]] = 0
+    name = "cfg5_n10_k512_ask16"
+    ref = Reference(10, 512, 0.5, 0)
+    ref.set_tables(frozen5, order5)
+    orc = Oracle(10, 512, 0.5, 0)
+    orc.set_tables(frozen5, order5)
+    out[f"{name}/frozen"] = np.packbits(frozen5)
+    out[f"{name}/order"] = order5
+    out[f"{name}/crcm"] = np.zeros(0, np.uint8)
+    rng = np.random.default_rng(5)
+    info = rng.integers(0, 2, (16, 512)).astype(np.uint8)
+    out[f"{name}/enc_info"] = np.packbits(info.reshape(-1))
+    out[f"{name}/enc_coded"] = np.packbits(np.stack([ref.encode(i) for i in info]).reshape(-1))
+    cm = []
+    for ci, (L, snr, B) in enumerate([(8, 12.0, 128), (8, 13.0, 128), (8, 14.0, 128), (1, 13.5, 128), (32, 12.5, 32)]):
+        trial0 = 1000 * ci
+        llr, sent = orc.synth_bicm_llr(3, SEED, trial0, B, snr)
+        dec = ref.decode_scl_llr(llr, L)
+        out[f"{name}/case{ci}/decoded"] = np.packbits(dec.reshape(-1))
+        cm.append({"L": L, "snr_db": snr, "constellation": 3, "B": B, "trial0": trial0,
+                   "llr_sha256": hashlib.sha256(llr.tobytes()).hexdigest(),
+                   "block_errors": int((dec != sent).any(axis=1).sum())})
+        print(name, cm[-1])
+    meta["codes"][name] = {"n": 10, "K": 512, "crc": 0, "eps": None, "explicit_tables": True, "cases": cm, "specials": [],
+                           "source": "PolarM/CodeConstructionData/..._13_ask16-gray_bicm_250000.txt"}
+
     # the reference's own deterministic driver output (main.cpp: n=11, K=1024, crc=0, eps=0.32,
     # Eb/N0 1:0.25:2, L = 1,2,4,8,32; 1000 runs, max_err 100) — SURVEY §6 / BASELINE.md §2
     libc.srand(1)

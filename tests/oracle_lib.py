@@ -182,6 +182,13 @@ class Oracle(_Base):
                    _p(llr, _dp), _p(info, _u8p))
         return llr, info
 
+    def synth_bicm_llr(self, cid, seed, trial0, B, snr_db):
+        llr = np.zeros((B, self.N), np.float64)
+        info = np.zeros((B, self.K), np.uint8)
+        self._call("synth_bicm_llr_batch", C.c_int(cid), C.c_uint64(seed), C.c_uint64(trial0), C.c_long(B),
+                   C.c_double(snr_db), _p(llr, _dp), _p(info, _u8p))
+        return llr, info
+
     def mc_batch(self, seed, t0, T, stride, ebno, Ls, enabled, err, run):
         ebno = np.ascontiguousarray(ebno, np.float64)
         Ls = np.ascontiguousarray(Ls, np.uint8)
@@ -189,3 +196,12 @@ class Oracle(_Base):
         assert err.dtype == np.uint64 and run.dtype == np.uint64
         self._call("mc_batch", C.c_uint64(seed), C.c_uint64(t0), C.c_long(T), C.c_long(stride), _p(ebno, _dp), C.c_int(len(ebno)),
                    _p(Ls, _u8p), C.c_int(len(Ls)), _p(enabled, _u8p), _p(err, _u64p), _p(run, _u64p))
+
+
+    def mc_batch_bicm(self, cid, seed, t0, T, stride, snr_db, Ls, enabled, err, run):
+        snr = np.ascontiguousarray(snr_db, np.float64)
+        Ls = np.ascontiguousarray(Ls, np.uint8)
+        enabled = np.ascontiguousarray(enabled, np.uint8)
+        self._call("mc_batch_bicm", C.c_int(cid), C.c_uint64(seed), C.c_uint64(t0), C.c_long(T), C.c_long(stride),
+                   _p(snr, _dp), C.c_int(len(snr)), _p(Ls, _u8p), C.c_int(len(Ls)), _p(enabled, _u8p),
+                   _p(err, _u64p), _p(run, _u64p))

