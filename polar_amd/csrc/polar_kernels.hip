@@ -190,6 +190,86 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : 4) void scl_decode_llr_
                 const int sh = n - lam;
                 const int S = 1 << sh;
                 const bool odd = (phi >> sh) & 1;
+                // ---- fused visit of two consecutive layers (lam: size S, op f/g; lam+1: size S/2, always
+                // f right after): the values of layer lam are written (the later g-visit of lam+1 needs
+                // them) but NOT re-read from HBM for the f-visit of lam+1. Only when the source of lam
+                // is HBM-resident (channel LLRs or a scratch layer).
+                if (!PIPE && S >= 8 && 2 * S > SL) {
+                    const int H = S / 2;
+                    if (active) {
+                        const bool in_is_ch = (lam == 1);
+                        const int pin = in_is_ch ? 0 : pL.get(sh + 1);
+                        const double *inp = in_is_ch ? nullptr : (g_llr + (size_t)(2 * S - 2 * SL) * 64 + gbase + pin);
+                        double *out0 = (S <= SL) ? (lds_llr + (size_t)(S - 1) * 64 + lane) : (g_llr + (size_t)(S - 2 * SL) * 64 + lane);
+                        double *out1 = (H <= SL) ? (lds_llr + (size_t)(H - 1) * 64 + lane) : (g_llr + (size_t)(H - 2 * SL) * 64 + lane);
+                        uint32_t cb0 = 0, cb1 = 0;          // partial-sum bits for elements j.. and j+H..
+                        const uint32_t *cwp = nullptr;
+                        if (odd) {
+                            if (S <= 32) { cb0 = (uint32_t)(clsmall >> S); cb1 = cb0 >> H; }
+                            else cwp = g_cl + (size_t)(S / 32 - 2) * 64 + gbase + pC.get(sh);
+                        }
+                        for (int j = 0; j < H; j += 4) {
+                            double a0[4], b0[4], a1[4], b1[4], x0[4], x1[4], y[4];
+                            if (in_is_ch) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    unsigned i0 = __brev((unsigned)(j + k)) >> (32 - n);
+                                    unsigned i1 = __brev((unsigned)(j + k + H)) >> (32 - n);
+                                    a0[k] = in0[i0]; b0[k] = in0[i0 + 1];
+                                    a1[k] = in0[i1]; b1[k] = in0[i1 + 1];
+                                }
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    a0[k] = inp[(size_t)(j + k) * 64];
+                                    b0[k] = inp[(size_t)(j + k + S) * 64];
+                                    a1[k] = inp[(size_t)(j + k + H) * 64];
+                                    b1[k] = inp[(size_t)(j + k + H + S) * 64];
+                                }
+                            }
+                            if (odd) {
+                                if (S > 32) {
+                                    if ((j & 31) == 0) {
+                                        cb0 = cwp[(size_t)(j >> 5) * 64];
+                                        cb1 = (H >= 32) ? cwp[(size_t)((j + H) >> 5) * 64] : (cb0 >> H);
+                                    }
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) {
+                                        x0[k] = g_node(a0[k], b0[k], (cb0 >> ((j + k) & 31)) & 1u);
+                                        x1[k] = g_node(a1[k], b1[k], (cb1 >> ((j + k) & 31)) & 1u);
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) {
+                                        x0[k] = g_node(a0[k], b0[k], (cb0 >> (j + k)) & 1u);
+                                        x1[k] = g_node(a1[k], b1[k], (cb1 >> (j + k)) & 1u);
+                                    }
+                                }
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    x0[k] = f_node(a0[k], b0[k], tb);
+                                    x1[k] = f_node(a1[k], b1[k], tb);
+                                }
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                out0[(size_t)(j + k) * 64] = x0[k];
+                                out0[(size_t)(j + k + H) * 64] = x1[k];
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) y[k] = f_node(x0[k], x1[k], tb);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) out1[(size_t)(j + k) * 64] = y[k];
+                        }
+                        pL.set(sh, lig);
+                        pL.set(sh - 1, lig);
+                    }
+                    wave_mem_fence();
+                    PROF(odd ? 1 : 2)
+                    ++lam;          // layer lam+1 is done
+                    continue;
+                }
                 if (active) {
                     // input layer lam-1 (size 2S): 0 = channel LLRs, else scratch/LDS slot
                     const int pin = (lam > 1) ? pL.get(sh + 1) : 0;
