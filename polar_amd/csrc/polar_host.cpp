@@ -86,6 +86,7 @@ struct polar_code {
     DevBuf<uint64_t> d_sel;
     // tuning
     int waves_per_cu = 0, lds_log = 0, pipe = -1;
+    bool prefix_on = true;
 };
 
 namespace {
@@ -333,6 +334,18 @@ int polar_decode_scl_llr_batch_dev(polar_code_t *h, const double *d_llr, long B,
     if ((rc = h->d_hist_scr.ensure((size_t)grid * h->W * 64 + 64))) return rc;
     PolarDecodeParams p;
     p.n = h->n; p.N = h->N; p.K = h->K; p.crc = h->crc; p.L = L; p.W = h->W; p.B = B;
+    {   // all-frozen prefix [0, P): handled cooperatively by the kernel when one codeword owns 32 lanes
+        int P = 0;
+        while (P < h->N && h->frozen[P]) ++P;
+        int Q = 0;
+        if (gs == 32 && h->prefix_on) {
+            if (P >= 256) Q = 256;
+            else { Q = 64; while (Q <= P) Q <<= 1; if (P < 33) Q = 0; }
+            if (Q > h->N / 2) Q = 0;
+        }
+        p.prefix_q = Q;
+        p.prefix_len = Q ? std::min(P, Q) : 0;
+    }
     p.llr = d_llr; p.p0 = nullptr; p.out = d_out; p.pm_out = d_pm;
     p.frozen = h->d_frozen.p; p.info_rank = h->d_info_rank.p; p.crc_mask = h->d_crc_mask.p; p.tabs = h->d_tabs.p;
     p.llr_scr = h->d_llr_scr.p; p.c_scr = h->d_c_scr.p; p.hist_scr = h->d_hist_scr.p;
@@ -382,6 +395,7 @@ int polar_decode_scl_p1_batch(polar_code_t *h, const double *p1, const double *p
     HIP_TRY(hipMemcpy(h->d_in.p + (size_t)B * N, p0, (size_t)B * N * sizeof(double), hipMemcpyHostToDevice));
     PolarDecodeParams p;
     p.n = h->n; p.N = N; p.K = h->K; p.crc = h->crc; p.L = L; p.W = h->W; p.B = B;
+    p.prefix_q = 0; p.prefix_len = 0;
     p.llr = h->d_in.p; p.p0 = h->d_in.p + (size_t)B * N; p.out = h->d_out.p; p.pm_out = nullptr;
     p.frozen = h->d_frozen.p; p.info_rank = h->d_info_rank.p; p.crc_mask = h->d_crc_mask.p; p.tabs = h->d_tabs.p;
     p.llr_scr = h->d_llr_scr.p; p.c_scr = h->d_c_scr.p; p.hist_scr = h->d_hist_scr.p;

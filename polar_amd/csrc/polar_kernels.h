@@ -7,6 +7,7 @@
 struct PolarDecodeParams {
     int n, N, K, crc, L;
     int W;                       // 32-bit words of decision history = ceil((K+crc)/32)
+    int prefix_q, prefix_len;    // all-frozen prefix handled cooperatively: block size Q (0 = off), leaves Pe
     long B;                      // codewords
     const double *llr;           // [B][N] device (LLR mode: llr; probability mode: p1)
     const double *p0;            // [B][N] device (probability mode only)

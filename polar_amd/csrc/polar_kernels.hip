@@ -180,11 +180,107 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : 4) void scl_decode_llr_
         unsigned t = 0;                            // unfrozen steps so far (wave-uniform)
         wave_mem_fence();
 
+        // ================= all-frozen prefix, cooperative (GS == 32 only) =================
+        // Until the first unfrozen position only ONE path exists per codeword and every decision is
+        // the frozen 0, so the LLRs of the first Pe leaves form a fixed dataflow of the channel LLRs.
+        // Instead of one lane walking it leaf by leaf (31 idle lanes), the 32 lanes of the group share
+        // the ELEMENTS: (1) the f-chain of the layers above the prefix block (node 0, sizes N/2..Q) is
+        // computed and stored in the standard layout; (2) the block of Q values is expanded by a
+        // log2(Q)-stage f/g butterfly in registers (u = 0 everywhere) into the Q leaf LLRs; (3) the
+        // path metric is accumulated over the leaves in order (same operations, same order as
+        // continuePaths_FrozenBit, PolarCode.cpp:475-487). The sequential walk resumes at phi = Pe.
+        int phi_start = 0, forced_top = 0;
+        if (GS == 32 && p.prefix_q > 0) {
+            const int Q = p.prefix_q, Pe = p.prefix_len;
+            const int R = Q >> 5;                              // values per lane (2..8)
+            const int own = gbase + L - 1;                     // slot of the single active path
+            double x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (valid) {
+                for (int S = N / 2; S >= Q; S >>= 1) {         // layers above the block: node 0, f of the layer above
+                    const bool from_ch = (2 * S == N);
+                    const double *inp = from_ch ? nullptr : ((2 * S <= SL) ? lds_llr + (size_t)(2 * S - 1) * 64 + own
+                                                                          : g_llr + (size_t)(2 * S - 2 * SL) * 64 + own);
+                    double *outp = (S <= SL) ? lds_llr + (size_t)(S - 1) * 64 + own : g_llr + (size_t)(S - 2 * SL) * 64 + own;
+                    for (int j = lig; j < S; j += 32) {
+                        double a, b;
+                        if (from_ch) {
+                            unsigned idx = __brev((unsigned)j) >> (32 - n);
+                            a = in0[idx]; b = in0[idx + 1];
+                        } else {
+                            a = inp[(size_t)j * 64]; b = inp[(size_t)(j + S) * 64];
+                        }
+                        const double r = f_node(a, b, tb);
+                        outp[(size_t)j * 64] = r;
+                        if (S == Q) {
+#pragma unroll
+                            for (int rr = 0; rr < 8; ++rr) if (rr == (j >> 5)) x[rr] = r;
+                        }
+                    }
+                    wave_mem_fence();
+                }
+            } else {
+                for (int S = N / 2; S >= Q; S >>= 1) wave_mem_fence();
+            }
+            // butterfly: stage with half-size h turns every node of size 2h into its f-child (lower
+            // half) and g-child (upper half, u = 0); value index i = r*32 + lig
+            for (int h = Q / 2; h >= 1; h >>= 1) {
+                if (h >= 32) {
+                    const int hr = h >> 5;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        if (r < R && (r & hr) == 0) {
+#pragma unroll
+                            for (int r2 = 0; r2 < 8; ++r2) {
+                                if (r2 == r + hr) {
+                                    const double lo = x[r], hi = x[r2];
+                                    x[r] = f_node(lo, hi, tb);
+                                    x[r2] = g_node(lo, hi, 0u);
+                                }
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        if (r < R) {
+                            const double mine = x[r];
+                            const double other = shfl_d(mine, lane ^ h);
+                            x[r] = (lig & h) ? g_node(other, mine, 0u) : f_node(mine, other, tb);
+                        }
+                    }
+                }
+            }
+            // path metric over the leaves 0..Pe-1 in order (leaf phi sits in x[phi>>5] of lane phi&31)
+            double acc = 0.0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                if (r < R && r * 32 < Pe) {
+                    const double spv = softplus_ref(-x[r], tb);
+                    const int cnt = (Pe - r * 32 < 32) ? (Pe - r * 32) : 32;
+                    for (int c = 0; c < cnt; ++c) acc += shfl_d(spv, gbase + c);
+                }
+            }
+            if (active) {
+                pm = acc;
+                // state the sequential walk expects: slot pointers of the stored layers, zero partial
+                // sums of every completed (all-frozen) left subtree
+                for (int S = N / 2; S >= Q; S >>= 1) pL.set(__builtin_ctz((unsigned)S), lig);
+                for (int S = 64; S <= Q && S <= N / 2; S <<= 1) {
+                    uint32_t *cz = g_cl + (size_t)(S / 32 - 2) * 64 + lane;
+                    for (int w = 0; w < S / 32; ++w) cz[(size_t)w * 64] = 0u;
+                    pC.set(__builtin_ctz((unsigned)S), lig);
+                }
+            }
+            wave_mem_fence();
+            phi_start = Pe;
+            if (Pe < Q) forced_top = n - __builtin_ctz((unsigned)Q) + 1;     // recompute from the block downwards
+        }
+
         PROF_DECL
-        for (int phi = 0; phi < N; ++phi) {
+        for (int phi = phi_start; phi < N; ++phi) {
             PROF(0)
             // ---------------- recursivelyCalcLLR(n, phi): PolarCode.cpp:422-455 ----------------
-            const int lam_top = phi ? (n - __builtin_ctz((unsigned)phi)) : 1;
+            const int lam_top = (phi == phi_start && forced_top) ? forced_top : (phi ? (n - __builtin_ctz((unsigned)phi)) : 1);
             double leaf = 0.0;
             for (int lam = lam_top; lam <= n; ++lam) {
                 const int sh = n - lam;
@@ -194,7 +290,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : 4) void scl_decode_llr_
                 // f right after): the values of layer lam are written (the later g-visit of lam+1 needs
                 // them) but NOT re-read from HBM for the f-visit of lam+1. Only when the source of lam
                 // is HBM-resident (channel LLRs or a scratch layer).
-                if (!PIPE && S >= 8 && 2 * S > SL) {
+                if (!PIPE && S >= 8 && 2 * S > SL && ((phi >> (sh - 1)) & 1) == 0) {   // (lam+1 is an f-visit)
                     const int H = S / 2;
                     if (active) {
                         const bool in_is_ch = (lam == 1);

@@ -188,3 +188,25 @@ def test_decode_sc_p1_matches_oracle(built_lib, oracle_built):
         assert (got[i] == o.decode_sc_p1(p1[i])).all(), i
     # agrees with the LLR decoder at L = 1 on ordinary inputs (SURVEY 8c cross-check)
     assert (got[10:] == g.decode_scl_llr(llr[10:], 1)).all()
+
+
+@pytest.mark.parametrize("n,K,crc", [(9, 256, 0), (10, 512, 8), (11, 1024, 16)])
+@pytest.mark.parametrize("L", [1, 4, 32])
+def test_winning_path_metric_matches_oracle(built_lib, oracle_built, n, K, crc, L):
+    """Floating-point side of the parity: the winning path metric (PolarCode.cpp:483,580-601 sums of
+    log(1+exp(.))) agrees with the oracle's fp64/glibc value to 1e-10 relative (tolerance for libm
+    vs the kernel's table-driven exp/log1p, ~1e-16 per term over <= N terms); the bits are exact."""
+    import torch
+    o, g = _pair(n, K, crc)
+    B = 24
+    llr, _ = o.synth_llr(808, 0, B, o.snr_sqrt_linear(1.5))
+    d = torch.tensor(llr, device="cuda")
+    out = torch.empty((B, K), dtype=torch.uint8, device="cuda")
+    pm = torch.zeros(B, dtype=torch.float64, device="cuda")
+    g.decode_scl_llr_dev(d.data_ptr(), B, L, out.data_ptr(), pm.data_ptr())
+    torch.cuda.synchronize()
+    got = pm.cpu().numpy()
+    for i in range(B):
+        bits, want = o.decode_scl_llr_pm(llr[i], L)
+        assert (out[i].cpu().numpy() == bits).all()
+        assert abs(got[i] - want) <= 1e-10 * max(1.0, abs(want)), (i, got[i], want)
