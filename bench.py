@@ -148,9 +148,10 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic_from_profile(args, B),
             "kernel_ms_avg": kern_avg_s * 1e3,
             "algorithmic_bytes_per_codeword": alg_bytes_per_cw,
+            "algorithmic_bytes_per_launch": B * alg_bytes_per_cw,
             "node_evals_per_s": (B * L * N * code.n) / kern_avg_s,
         },
     }
@@ -161,6 +162,20 @@ def main():
         print(json.dumps(res))
     if dist:
         dist.destroy_process_group()
+
+
+def traffic_from_profile(args, B):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic.json, written by tools/update_traffic.py from a tools/profile.sh run of this
+    very command) — only when it was taken on the same workload; otherwise null."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        c = t["config"]
+        if (c["n"], c["K"], c["crc"], c["L"], c["batch"]) == (args.n, args.K, args.crc, args.L, B):
+            return t["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(args, code, llr, out):

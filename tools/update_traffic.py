@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Record the HBM traffic per launch (rocprofv3 PMC passes, corrected as MI355X_MICROARCH.md §HBM
+prescribes — see tools/pmc_summary.py) for the bench.py default workload, so that bench.py can
+report roofline.traffic next to the live-measured kernel time.
+usage: tools/update_traffic.py profiles/r01/<name>_pmc.json n K crc L batch"""
+import json
+import sys
+
+src, n, K, crc, L, batch = sys.argv[1], *map(int, sys.argv[2:7])
+d = json.load(open(src))
+out = {"config": {"n": n, "K": K, "crc": crc, "L": L, "batch": batch},
+       "traffic_bytes_per_launch": d["hbm_traffic_per_launch"]["total_bytes"],
+       "read_bytes_corrected": d["hbm_traffic_per_launch"]["read_bytes_corrected"],
+       "write_bytes": d["hbm_traffic_per_launch"]["write_bytes"],
+       "kernel_avg_ns_in_profile": d["kernel_time"]["avg_ns"],
+       "source": src, "command": d["command"]}
+json.dump(out, open("profiles/traffic.json", "w"), indent=1)
+print(out)
