@@ -51,15 +51,21 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    import polar_amd
     from polar_amd import build
-    build.build()
+    if rank == 0:
+        build.build()            # in-tree .so normally travels prebuilt; only one rank may compile
+    if dist:
+        dist.barrier()
+    import polar_amd
 
     # the code: Bhattacharyya construction as the reference's main.cpp (eps = 0.32); the CRC matrix
     # comes from glibc rand() after srand(1) — identical on every rank
@@ -158,10 +164,12 @@ def main():
 
     if rank == 0 and world == 1 and args.cpu_sample != 0:
         res["cpu_baseline"] = cpu_baseline(args, code, llr, out)
-    if rank == 0:
-        print(json.dumps(res))
     if dist:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(res), flush=True)     # the ONE JSON line, last thing on stdout
 
 
 def traffic_from_profile(args, B):
