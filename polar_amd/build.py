@@ -62,6 +62,8 @@ def build(force=False, verbose=False, profile=False):
                    "-Wall", "-Wno-unused-function", "-x", "hip", "-I", INC, "-I", CSRC, "-c", src, "-o", obj]
             if profile:
                 cmd.insert(1, "-DPOLAR_PROFILE")
+            for d in os.environ.get("POLAR_DEFS", "").split():
+                cmd.insert(1, "-D" + d)
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

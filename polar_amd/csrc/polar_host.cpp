@@ -291,7 +291,7 @@ int polar_set_crc_matrix(polar_code_t *h, const uint8_t *m) {
 int polar_set_tuning(polar_code_t *h, int waves_per_cu, int lds_log) {
     if (!h) return fail(POLAR_E_ARG, "NULL handle");
     if (waves_per_cu < 0 || waves_per_cu > 32) return fail(POLAR_E_ARG, "waves_per_cu out of range");
-    if (lds_log != 0 && (lds_log < 3 || lds_log > 5)) return fail(POLAR_E_ARG, "lds_log must be 0 or 3..5");
+    if (lds_log != 0 && (lds_log < 2 || lds_log > 5)) return fail(POLAR_E_ARG, "lds_log must be 0 or 2..5");
     h->waves_per_cu = waves_per_cu;
     h->lds_log = lds_log;
     return POLAR_OK;

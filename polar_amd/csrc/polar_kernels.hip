@@ -123,8 +123,14 @@ __device__ __forceinline__ double softplus_ref(double x, const Tabs &tb) {
 //
 // GS  : lanes per codeword (power of two >= L)
 // LDS_LOG : log2 of the largest layer size kept in LDS
+#ifndef FU
+#define FU 4
+#endif
+#ifndef OCC
+#define OCC 4
+#endif
 template <int GS, int LDS_LOG, int PIPE>
-__global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : 4) void scl_decode_llr_kernel(PolarDecodeParams p) {
+__global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_llr_kernel(PolarDecodeParams p) {
     // PIPE=1: one wave per block (8 waves/CU, register double-buffering); PIPE=0: four independent
     // waves per block sharing the transcendental tables (16 waves/CU with LDS_LOG = 3)
     constexpr int WPB = PIPE ? 1 : 4;
@@ -304,11 +310,11 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : 4) void scl_decode_llr_
                             if (S <= 32) { cb0 = (uint32_t)(clsmall >> S); cb1 = cb0 >> H; }
                             else cwp = g_cl + (size_t)(S / 32 - 2) * 64 + gbase + pC.get(sh);
                         }
-                        for (int j = 0; j < H; j += 4) {
-                            double a0[4], b0[4], a1[4], b1[4], x0[4], x1[4], y[4];
+                        for (int j = 0; j < H; j += FU) {
+                            double a0[FU], b0[FU], a1[FU], b1[FU], x0[FU], x1[FU], y[FU];
                             if (in_is_ch) {
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) {
+                                for (int k = 0; k < FU; ++k) {
                                     unsigned i0 = __brev((unsigned)(j + k)) >> (32 - n);
                                     unsigned i1 = __brev((unsigned)(j + k + H)) >> (32 - n);
                                     a0[k] = in0[i0]; b0[k] = in0[i0 + 1];
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : 4) void scl_decode_llr_
                                 }
                             } else {
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) {
+                                for (int k = 0; k < FU; ++k) {
                                     a0[k] = inp[(size_t)(j + k) * 64];
                                     b0[k] = inp[(size_t)(j + k + S) * 64];
                                     a1[k] = inp[(size_t)(j + k + H) * 64];
@@ -330,33 +336,33 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : 4) void scl_decode_llr_
                                         cb1 = (H >= 32) ? cwp[(size_t)((j + H) >> 5) * 64] : (cb0 >> H);
                                     }
 #pragma unroll
-                                    for (int k = 0; k < 4; ++k) {
+                                    for (int k = 0; k < FU; ++k) {
                                         x0[k] = g_node(a0[k], b0[k], (cb0 >> ((j + k) & 31)) & 1u);
                                         x1[k] = g_node(a1[k], b1[k], (cb1 >> ((j + k) & 31)) & 1u);
                                     }
                                 } else {
 #pragma unroll
-                                    for (int k = 0; k < 4; ++k) {
+                                    for (int k = 0; k < FU; ++k) {
                                         x0[k] = g_node(a0[k], b0[k], (cb0 >> (j + k)) & 1u);
                                         x1[k] = g_node(a1[k], b1[k], (cb1 >> (j + k)) & 1u);
                                     }
                                 }
                             } else {
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) {
+                                for (int k = 0; k < FU; ++k) {
                                     x0[k] = f_node(a0[k], b0[k], tb);
                                     x1[k] = f_node(a1[k], b1[k], tb);
                                 }
                             }
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) {
+                            for (int k = 0; k < FU; ++k) {
                                 out0[(size_t)(j + k) * 64] = x0[k];
                                 out0[(size_t)(j + k + H) * 64] = x1[k];
                             }
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) y[k] = f_node(x0[k], x1[k], tb);
+                            for (int k = 0; k < FU; ++k) y[k] = f_node(x0[k], x1[k], tb);
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) out1[(size_t)(j + k) * 64] = y[k];
+                            for (int k = 0; k < FU; ++k) out1[(size_t)(j + k) * 64] = y[k];
                         }
                         pL.set(sh, lig);
                         pL.set(sh - 1, lig);
@@ -722,6 +728,7 @@ static hipError_t launch_gs(const PolarDecodeParams &p, int lds_log, int pipe, i
     const int wpb = polar_decode_waves_per_block(pipe);
 #define POLAR_LAUNCH(LL, PP) hipLaunchKernelGGL((scl_decode_llr_kernel<GS, LL, PP>), dim3(grid / wpb), dim3(64 * wpb), lds, st, p)
     switch (lds_log * 2 + (pipe ? 1 : 0)) {
+        case 4: POLAR_LAUNCH(2, 0); break;
         case 6: POLAR_LAUNCH(3, 0); break;
         case 7: POLAR_LAUNCH(3, 1); break;
         case 8: POLAR_LAUNCH(4, 0); break;
