@@ -115,6 +115,23 @@ __device__ __forceinline__ double softplus_ref(double x, const Tabs &tb) {
     return (x > 0) ? x + hx : hx;
 }
 
+// log(1+e^-a) and log(1+e^a) for a = |llr| >= 0 with ONE h evaluation; `skip` (wave-uniform: every
+// lane has a >= 37) avoids the transcendental altogether: log(1+e^-a) is exactly 0 there and
+// a + 0 = a (softplus_ref above), +inf beyond the fp64 exp overflow point.
+__device__ __forceinline__ void softplus_pair(double a, bool skip, const Tabs &tb, double &sneg, double &spos) {
+    double hx = 0.0;
+    if (!skip) {
+        if (a < 9.5367431640625e-07) {            // noise regime: literal expressions (see f_node)
+            sneg = softplus_literal(-a);
+            spos = softplus_literal(a);
+            return;
+        }
+        hx = h_fn(a, tb);
+    }
+    sneg = hx;
+    spos = (a > 709.782712893384) ? __builtin_inf() : a + hx;
+}
+
 }  // namespace
 
 // Layer storage helpers --------------------------------------------------------------------
@@ -504,8 +521,11 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 // path computes); bad metric = PM + log(1+e^|llr|) >= (PM + |llr|)(1 - 2^-40).
                 const double al = fabs(leaf);
                 double gm = -__builtin_inf(), bl = __builtin_inf();
+                double sneg = 0.0, spos = 0.0;             // log(1+e^-|llr|), log(1+e^|llr|)
+                const bool sp_skip = __all(!active || al >= 37.0);
                 if (active) {
-                    gm = pm + softplus_ref(-al, tb);
+                    softplus_pair(al, sp_skip, tb, sneg, spos);
+                    gm = pm + sneg;
                     bl = (pm + al) * 0.99999999999909050530;
                 }
                 const double gmax = group_reduce<GS, true>(gm, lane);
@@ -520,8 +540,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 } else {
                 double pf0 = __builtin_nan(""), pf1 = __builtin_nan("");
                 if (active) {
-                    pf0 = -(pm + softplus_ref(-leaf, tb));
-                    pf1 = -(pm + softplus_ref(leaf, tb));
+                    pf0 = -(pm + ((leaf < 0) ? spos : sneg));     // -(PM + log(1+e^-llr)), PolarCode.cpp:505
+                    pf1 = -(pm + ((leaf < 0) ? sneg : spos));     // -(PM + log(1+e^llr)),  PolarCode.cpp:506
                 }
                 bool c0 = active, c1 = active;
                 const bool need = (2 * nact > L);          // otherwise every fork continues
