@@ -507,8 +507,13 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
             unsigned ubit = 0;
             if (frozen) {
                 // continuePaths_FrozenBit: PolarCode.cpp:475-487
-                if (!__all(!active || leaf >= 37.0)) {
-                    if (active) pm += softplus_ref(-leaf, tb);
+                // PM += log(1+e^-llr): exactly 0 for llr >= 37, exactly |llr| (+0) for llr <= -37
+                const double alz = fabs(leaf);
+                const bool fz_skip = __all(!active || alz >= 37.0);
+                if (active) {
+                    double sneg, spos;
+                    softplus_pair(alz, fz_skip, tb, sneg, spos);
+                    pm += (leaf < 0) ? spos : sneg;
                 }
             } else {
                 // continuePaths_UnfrozenBit: PolarCode.cpp:489-607
