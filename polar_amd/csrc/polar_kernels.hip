@@ -550,7 +550,51 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 }
                 bool c0 = active, c1 = active;
                 const bool need = (2 * nact > L);          // otherwise every fork continues
-                if (__any(need)) {
+                const bool full = (nact == L);
+                if (!__any(need && !full)) {
+                    // List full (the usual case). Rank = number of better forks in the reference's order
+                    // (metric desc = PM asc, fork index asc on ties, PolarCode.cpp:528-553). A bad fork
+                    // whose lower bound is worse than every good fork (bl > gmax) can neither survive nor
+                    // outrank a survivor, so only the L good forks and the few "competitive" bad forks
+                    // are compared against: 32 LDS broadcasts + a short scalar loop instead of 64.
+                    const bool goodbit = (leaf < 0);                       // bit the leaf LLR favours
+                    const double mg = goodbit ? -pf1 : -pf0;                // PM of my good / bad fork
+                    const double mb = goodbit ? -pf0 : -pf1;
+                    const int ig = 2 * lig + (goodbit ? 1 : 0), ib = 2 * lig + (goodbit ? 0 : 1);
+                    const bool cbad = active && full && !(bl > gmax);
+                    const u64 cbm = __ballot(cbad);
+                    const u64 gbits = __ballot(goodbit) >> gbase;
+                    sortbuf[lane] = mg;
+                    wave_mem_fence();
+                    int rg = 0, rb = 0;
+                    const double *sb = sortbuf + gbase;
+#pragma unroll 4
+                    for (int i = 0; i < GS; ++i) {
+                        const double v = sb[i];
+                        const int jg = 2 * i + (int)((gbits >> i) & 1ull);
+                        rg += (v < mg) || (v == mg && jg < ig);
+                        rb += (v < mb) || (v == mb && jg < ib);
+                    }
+                    u64 m = cbm;
+                    while (m) {
+                        const int i = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const double vb = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mb), i),
+                                                           __builtin_amdgcn_readlane(__double2loint(mb), i));
+                        const int gi = __builtin_amdgcn_readlane((int)goodbit, i);
+                        const int jb = 2 * (i & (GS - 1)) + (gi ? 0 : 1);
+                        const bool same = ((i & ~(GS - 1)) == gbase);
+                        rg += same && ((vb < mg) || (vb == mg && jb < ig));
+                        rb += same && ((vb < mb) || (vb == mb && jb < ib));
+                    }
+                    if (full) {
+                        const bool sg = active && (rg < L);
+                        const bool sbd = cbad && (rb < L);
+                        c0 = goodbit ? sbd : sg;
+                        c1 = goodbit ? sg : sbd;
+                    }
+                    wave_mem_fence();
+                } else {
                     sortbuf[2 * lane] = pf0;
                     sortbuf[2 * lane + 1] = pf1;
                     wave_mem_fence();
