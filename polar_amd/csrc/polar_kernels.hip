@@ -55,12 +55,16 @@ namespace {
 // 1+e^-x rounds to 1), f(0,b) == 0 exactly, f is symmetric, log(1+e^x) -> +inf for x > 709.78.
 struct Tabs { const double *T, *RC, *LC; };   // LDS: T[64], RC[129], LC[129]
 
+// NOTE: the Horner starts below are written as a separate multiply and add on purpose. A fused
+// fma(x, c1, c2) has two constant operands, one of which must sit in a VGPR pair; the compiler hoists
+// that pair out of every loop, runs out of registers and RELOADS it from scratch (with a full
+// s_waitcnt vmcnt(0)) inside each f-node. mul-by-constant + add-constant needs no VGPR constant.
 __device__ __forceinline__ double exp_neg(double x, const Tabs &tb) {   // e^-x, x >= 0
     const double kd = __builtin_rint(x * 92.332482616893657);            // 64/ln2
     const int k = (int)kd;
     double r = __builtin_fma(kd, -0.010830424696223417, x);              // ln2/64, high part (low 16 bits zero)
     r = __builtin_fma(kd, -2.5728046223276688e-14, r);                   // ln2/64, low part
-    double p = __builtin_fma(r, -1.0 / 120.0, 1.0 / 24.0);
+    double p = r * (-1.0 / 120.0) + 1.0 / 24.0;
     p = __builtin_fma(p, r, -1.0 / 6.0);
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, -1.0);
@@ -72,7 +76,7 @@ __device__ __forceinline__ double log_1p2(double m, const Tabs &tb) {    // log(
     const int j = (int)jd;
     const double c = __builtin_fma(jd, 0.0078125, 1.0);
     const double q = (m - c) * tb.RC[j];
-    double p = __builtin_fma(q, -1.0 / 6.0, 0.2);
+    double p = q * (-1.0 / 6.0) + 0.2;
     p = __builtin_fma(p, q, -0.25);
     p = __builtin_fma(p, q, 1.0 / 3.0);
     p = __builtin_fma(p, q, -0.5);
@@ -302,10 +306,56 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         PROF_DECL
         for (int phi = phi_start; phi < N; ++phi) {
             PROF(0)
+            // recursivelyUpdateC (PolarCode.cpp:457-473) from the layer of size S upwards: X = column 1 of
+            // that layer (the S bits just completed by a RIGHT child with node index ph)
+            auto update_c = [&](int S, uint32_t X, int ph) {
+                for (;;) {
+                    if (4 * S > N) break;                   // C_0 is never read (PolarCode.cpp writes it, nobody uses it)
+                    const int psi = ph >> 1;
+                    const bool to_right = (psi & 1);        // result becomes column 1 of C_{lam-1}
+                    const int sh = __builtin_ctz((unsigned)S);
+                    if (S <= 16) {
+                        uint32_t cl = (uint32_t)(clsmall >> S) & ((1u << S) - 1u);
+                        uint32_t nw = (cl ^ X) | (X << S);   // 2S bits
+                        if (!to_right) {
+                            const int S2 = 2 * S;
+                            const u64 m = ((S2 == 32) ? 0xFFFFFFFFull : ((1ull << S2) - 1ull)) << S2;
+                            if (active) clsmall = (clsmall & ~m) | ((u64)nw << S2);
+                        }
+                        X = nw;
+                    } else if (S == 32) {
+                        uint32_t cl = (uint32_t)(clsmall >> 32);
+                        uint32_t *dst = (to_right ? g_cr : g_cl) + (size_t)0 * 64 + lane;   // layer size 64 -> word offset 0
+                        if (active) { dst[0] = cl ^ X; dst[64] = X; }
+                        if (!to_right && active) pC.set(sh + 1, lig);
+                    } else {
+                        const int nwd = S / 32;
+                        const uint32_t *cl = g_cl + (size_t)(nwd - 2) * 64 + gbase + pC.get(sh);
+                        const uint32_t *cr = g_cr + (size_t)(nwd - 2) * 64 + lane;
+                        uint32_t *dst = (to_right ? g_cr : g_cl) + (size_t)(2 * nwd - 2) * 64 + lane;
+                        if (active) {
+                            for (int w = 0; w < nwd; ++w) {
+                                uint32_t r = cr[(size_t)w * 64];
+                                uint32_t l = cl[(size_t)w * 64];
+                                dst[(size_t)w * 64] = l ^ r;
+                                dst[(size_t)(w + nwd) * 64] = r;
+                            }
+                            if (!to_right) pC.set(sh + 1, lig);
+                        }
+                    }
+                    wave_mem_fence();
+                    if (!to_right) break;
+                    S *= 2;
+                    ph = psi;
+                }
+            };
+            // all-frozen aligned block of 2^zb leaves starting here (host schedule), 0 = ordinary leaf
+            const int zb = p.sched ? (int)p.sched[phi] : 0;
+            const int lam_stop = n - zb;
             // ---------------- recursivelyCalcLLR(n, phi): PolarCode.cpp:422-455 ----------------
             const int lam_top = (phi == phi_start && forced_top) ? forced_top : (phi ? (n - __builtin_ctz((unsigned)phi)) : 1);
             double leaf = 0.0;
-            for (int lam = lam_top; lam <= n; ++lam) {
+            for (int lam = lam_top; lam <= lam_stop; ++lam) {
                 const int sh = n - lam;
                 const int S = 1 << sh;
                 const bool odd = (phi >> sh) & 1;
@@ -313,7 +363,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 // f right after): the values of layer lam are written (the later g-visit of lam+1 needs
                 // them) but NOT re-read from HBM for the f-visit of lam+1. Only when the source of lam
                 // is HBM-resident (channel LLRs or a scratch layer).
-                if (!PIPE && S >= 8 && 2 * S > SL && ((phi >> (sh - 1)) & 1) == 0) {   // (lam+1 is an f-visit)
+                if (!PIPE && S >= 8 && 2 * S > SL && lam + 1 <= lam_stop && ((phi >> (sh - 1)) & 1) == 0) {   // (lam+1 is an f-visit)
                     const int H = S / 2;
                     if (active) {
                         const bool in_is_ch = (lam == 1);
@@ -328,7 +378,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                             else cwp = g_cl + (size_t)(S / 32 - 2) * 64 + gbase + pC.get(sh);
                         }
                         for (int j = 0; j < H; j += FU) {
-                            double a0[FU], b0[FU], a1[FU], b1[FU], x0[FU], x1[FU], y[FU];
+                            double a0[FU], b0[FU], a1[FU], b1[FU];
                             if (in_is_ch) {
 #pragma unroll
                                 for (int k = 0; k < FU; ++k) {
@@ -346,40 +396,26 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                                     b1[k] = inp[(size_t)(j + k + H + S) * 64];
                                 }
                             }
-                            if (odd) {
-                                if (S > 32) {
-                                    if ((j & 31) == 0) {
-                                        cb0 = cwp[(size_t)(j >> 5) * 64];
-                                        cb1 = (H >= 32) ? cwp[(size_t)((j + H) >> 5) * 64] : (cb0 >> H);
-                                    }
-#pragma unroll
-                                    for (int k = 0; k < FU; ++k) {
-                                        x0[k] = g_node(a0[k], b0[k], (cb0 >> ((j + k) & 31)) & 1u);
-                                        x1[k] = g_node(a1[k], b1[k], (cb1 >> ((j + k) & 31)) & 1u);
-                                    }
-                                } else {
-#pragma unroll
-                                    for (int k = 0; k < FU; ++k) {
-                                        x0[k] = g_node(a0[k], b0[k], (cb0 >> (j + k)) & 1u);
-                                        x1[k] = g_node(a1[k], b1[k], (cb1 >> (j + k)) & 1u);
-                                    }
-                                }
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < FU; ++k) {
-                                    x0[k] = f_node(a0[k], b0[k], tb);
-                                    x1[k] = f_node(a1[k], b1[k], tb);
-                                }
+                            if (odd && S > 32 && (j & 31) == 0) {
+                                cb0 = cwp[(size_t)(j >> 5) * 64];
+                                cb1 = (H >= 32) ? cwp[(size_t)((j + H) >> 5) * 64] : (cb0 >> H);
                             }
+                            // element by element: (x0, x1) of layer lam -> stored -> y of layer lam+1 -> stored
 #pragma unroll
                             for (int k = 0; k < FU; ++k) {
-                                out0[(size_t)(j + k) * 64] = x0[k];
-                                out0[(size_t)(j + k + H) * 64] = x1[k];
+                                double x0, x1;
+                                if (odd) {
+                                    const int bi = (S > 32) ? ((j + k) & 31) : (j + k);
+                                    x0 = g_node(a0[k], b0[k], (cb0 >> bi) & 1u);
+                                    x1 = g_node(a1[k], b1[k], (cb1 >> bi) & 1u);
+                                } else {
+                                    x0 = f_node(a0[k], b0[k], tb);
+                                    x1 = f_node(a1[k], b1[k], tb);
+                                }
+                                out0[(size_t)(j + k) * 64] = x0;
+                                out0[(size_t)(j + k + H) * 64] = x1;
+                                out1[(size_t)(j + k) * 64] = f_node(x0, x1, tb);
                             }
-#pragma unroll
-                            for (int k = 0; k < FU; ++k) y[k] = f_node(x0[k], x1[k], tb);
-#pragma unroll
-                            for (int k = 0; k < FU; ++k) out1[(size_t)(j + k) * 64] = y[k];
                         }
                         pL.set(sh, lig);
                         pL.set(sh - 1, lig);
@@ -502,6 +538,68 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 PROF(S > SL ? (odd ? 1 : 2) : (S >= 4 ? 3 : 4))
             }
 
+
+            if (zb) {
+                // ---- rate-0 block: Z = 2^zb consecutive frozen leaves whose subtree hangs off the layer of
+                // size Z that was just computed. Every decision inside is the frozen 0, so the Z leaf LLRs
+                // are a fixed f/g dataflow of that layer (g with u = 0): evaluated level by level in
+                // registers (ILP Z/2) instead of Z sequential leaf steps; the path metric is then updated
+                // leaf by leaf in order (PolarCode.cpp:475-487), and the block's partial sums (Z zeros) are
+                // handed to the layer of size Z exactly as the last leaf's recursivelyUpdateC would.
+                const int Z = 1 << zb;
+                // one 4-leaf sub-block: values v0..v3 of a size-4 node -> leaves (f,f) (f,g) (g,f) (g,g), then
+                // the metric update of those four leaves in order
+                auto block4 = [&](double v0, double v1, double v2, double v3) {
+                    double lf[4] = {0, 0, 0, 0};
+                    if (active) {
+                        const double a0 = f_node(v0, v2, tb), a1 = f_node(v1, v3, tb);
+                        const double b0 = g_node(v0, v2, 0u), b1 = g_node(v1, v3, 0u);
+                        lf[0] = f_node(a0, a1, tb); lf[1] = g_node(a0, a1, 0u);
+                        lf[2] = f_node(b0, b1, tb); lf[3] = g_node(b0, b1, 0u);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const double alz = fabs(lf[i]);
+                        const bool fz_skip = __all(!active || alz >= 37.0);
+                        if (active) {
+                            double sneg, spos;
+                            softplus_pair(alz, fz_skip, tb, sneg, spos);
+                            pm += (lf[i] < 0) ? spos : sneg;
+                        }
+                    }
+                };
+                const double *yp = (Z <= SL) ? (lds_llr + (size_t)(Z - 1) * 64 + lane) : (g_llr + (size_t)(Z - 2 * SL) * 64 + lane);
+                if (zb == 3) {
+                    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+                    if (active) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const double lo = yp[(size_t)j * 64], hi = yp[(size_t)(j + 4) * 64];
+                            a[j] = f_node(lo, hi, tb);
+                            b[j] = g_node(lo, hi, 0u);
+                        }
+                    }
+                    block4(a[0], a[1], a[2], a[3]);
+                    block4(b[0], b[1], b[2], b[3]);
+                } else {
+                    double y[4] = {0, 0, 0, 0};
+                    if (active) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) y[j] = yp[(size_t)j * 64];
+                    }
+                    block4(y[0], y[1], y[2], y[3]);
+                }
+                const int nu = phi >> zb;                     // node index of the block at its layer
+                if ((nu & 1) == 0) {
+                    if (active) clsmall &= ~((((u64)1 << Z) - 1ull) << Z);   // column 0 of that layer := 0
+                } else {
+                    update_c(Z, 0u, nu);
+                }
+                wave_mem_fence();
+                PROF(5)
+                phi += Z - 1;
+                continue;
+            }
             // ---------------- leaf: frozen / unfrozen ----------------
             const bool frozen = p.frozen[phi] != 0;   // wave-uniform
             unsigned ubit = 0;
@@ -568,13 +666,21 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     wave_mem_fence();
                     int rg = 0, rb = 0;
                     const double *sb = sortbuf + gbase;
-#pragma unroll 4
+                    // good fork of path i (index 2i + bit) vs my forks (indices 2*lig + ...): it precedes them
+                    // on a tie exactly when i < lig (for i == lig see below), so the tie-break folds into the
+                    // choice between "<=" and "<"; comparisons produce wave masks, combined on the scalar unit
+#pragma unroll 8
                     for (int i = 0; i < GS; ++i) {
                         const double v = sb[i];
-                        const int jg = 2 * i + (int)((gbits >> i) & 1ull);
-                        rg += (v < mg) || (v == mg && jg < ig);
-                        rb += (v < mb) || (v == mb && jg < ib);
+                        const u64 below_me = __ballot(lig > i);                    // lanes for which i < lig
+                        const u64 lt_g = __builtin_amdgcn_fcmp(v, mg, 4), le_g = __builtin_amdgcn_fcmp(v, mg, 5);
+                        const u64 lt_b = __builtin_amdgcn_fcmp(v, mb, 4), le_b = __builtin_amdgcn_fcmp(v, mb, 5);
+                        rg += (int)__builtin_amdgcn_inverse_ballot_w64((le_g & below_me) | (lt_g & ~below_me));
+                        rb += (int)__builtin_amdgcn_inverse_ballot_w64((le_b & below_me) | (lt_b & ~below_me));
                     }
+                    // i == lig: my own good fork is never counted against itself (v < mg is false); against my
+                    // bad fork the strict part (mg < mb) was counted above, a tie goes to the lower fork index
+                    rb += (mg == mb && !goodbit) ? 1 : 0;
                     u64 m = cbm;
                     while (m) {
                         const int i = __builtin_ctzll(m);
@@ -621,15 +727,26 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 const u64 km = (__ballot(kill) >> gbase) & gmask;
                 const u64 bm = (__ballot(both) >> gbase) & gmask;
                 srcof[lane] = (unsigned char)lig;
-                if (kill) stackv[gbase + sp + __popcll(km & below)] = (unsigned char)lig;
-                sp += __popcll(km);
-                wave_mem_fence();
-                if (both) {
-                    int lp = stackv[gbase + sp - 1 - __popcll(bm & below)];
-                    srcof[gbase + lp] = (unsigned char)lig;
+                if (__all(!active || full)) {
+                    // list full before the step => #kills == #clones: the kills are pushed (ascending l) and
+                    // popped right back (LIFO) by the clones in ascending l, i.e. the r-th cloner revives the
+                    // r-th LARGEST killed index; stack pointer and the entries below are untouched. One LDS
+                    // round trip: cloners post their index by rank, killed lanes pick theirs up.
+                    if (both) stackv[gbase + __popcll(bm & below)] = (unsigned char)lig;           // rank r -> cloner
+                    wave_mem_fence();
+                    if (kill) srcof[lane] = stackv[gbase + __popcll(km >> 1 >> lig)];             // #killed above me = my rank from the top
+                    wave_mem_fence();
+                } else {
+                    if (kill) stackv[gbase + sp + __popcll(km & below)] = (unsigned char)lig;
+                    sp += __popcll(km);
+                    wave_mem_fence();
+                    if (both) {
+                        int lp = stackv[gbase + sp - 1 - __popcll(bm & below)];
+                        srcof[gbase + lp] = (unsigned char)lig;
+                    }
+                    sp -= __popcll(bm);
+                    wave_mem_fence();
                 }
-                sp -= __popcll(bm);
-                wave_mem_fence();
                 const int src = srcof[lane];
                 const bool is_clone = (src != lig);
                 // PM of the surviving forks: PM + log(1+exp(-+llr)) is the very sum whose negation
@@ -662,11 +779,16 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 if ((t & 31) == 31) {
                     const int w = (int)(t >> 5);
                     if (__any(active && origin != lig)) {
-                        for (int wi = 0; wi < w; ++wi) {
-                            uint32_t v = 0;
-                            if (active) v = g_hist[(size_t)wi * 64 + gbase + origin];
+                        // permuted copy of the flushed words, 8 at a time: all loads of a batch are in flight
+                        // together, then all stores (a word row is read by every lane before any lane writes it)
+                        for (int w0 = 0; w0 < w; w0 += 8) {
+                            uint32_t v[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) v[q] = (active && w0 + q < w) ? g_hist[(size_t)(w0 + q) * 64 + gbase + origin] : 0u;
                             wave_mem_fence();
-                            if (active) g_hist[(size_t)wi * 64 + lane] = v;
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) if (active && w0 + q < w) g_hist[(size_t)(w0 + q) * 64 + lane] = v[q];
+                            wave_mem_fence();
                         }
                     }
                     if (active) { g_hist[(size_t)w * 64 + lane] = hword; origin = lig; hword = 0; }
@@ -681,48 +803,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 // left leaf: column 0 of C_n (size 1) lives at bit 1 of clsmall
                 if (active) clsmall = (clsmall & ~2ull) | ((u64)ubit << 1);
             } else {
-                // recursivelyUpdateC(n, phi): PolarCode.cpp:457-473. X = column 1 of C_lam.
-                int S = 1, ph = phi;
-                uint32_t X = ubit;   // valid while S <= 32
-                for (;;) {
-                    if (4 * S > N) break;                   // C_0 is never read (PolarCode.cpp writes it, nobody uses it)
-                    const int psi = ph >> 1;
-                    const bool to_right = (psi & 1);        // result becomes column 1 of C_{lam-1}
-                    const int sh = __builtin_ctz((unsigned)S);
-                    if (S <= 16) {
-                        uint32_t cl = (uint32_t)(clsmall >> S) & ((1u << S) - 1u);
-                        uint32_t nw = (cl ^ X) | (X << S);   // 2S bits
-                        if (!to_right) {
-                            const int S2 = 2 * S;
-                            const u64 m = ((S2 == 32) ? 0xFFFFFFFFull : ((1ull << S2) - 1ull)) << S2;
-                            if (active) clsmall = (clsmall & ~m) | ((u64)nw << S2);
-                        }
-                        X = nw;
-                    } else if (S == 32) {
-                        uint32_t cl = (uint32_t)(clsmall >> 32);
-                        uint32_t *dst = (to_right ? g_cr : g_cl) + (size_t)0 * 64 + lane;   // layer size 64 -> word offset 0
-                        if (active) { dst[0] = cl ^ X; dst[64] = X; }
-                        if (!to_right && active) pC.set(sh + 1, lig);
-                    } else {
-                        const int nwd = S / 32;
-                        const uint32_t *cl = g_cl + (size_t)(nwd - 2) * 64 + gbase + pC.get(sh);
-                        const uint32_t *cr = g_cr + (size_t)(nwd - 2) * 64 + lane;
-                        uint32_t *dst = (to_right ? g_cr : g_cl) + (size_t)(2 * nwd - 2) * 64 + lane;
-                        if (active) {
-                            for (int w = 0; w < nwd; ++w) {
-                                uint32_t r = cr[(size_t)w * 64];
-                                uint32_t l = cl[(size_t)w * 64];
-                                dst[(size_t)w * 64] = l ^ r;
-                                dst[(size_t)(w + nwd) * 64] = r;
-                            }
-                            if (!to_right) pC.set(sh + 1, lig);
-                        }
-                    }
-                    wave_mem_fence();
-                    if (!to_right) break;
-                    S *= 2;
-                    ph = psi;
-                }
+                update_c(1, ubit, phi);
             }
             PROF(7)
         }  // phi
@@ -732,11 +813,14 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         {
             const int w = (int)(t >> 5);   // complete words
             if (__any(active && origin != lig)) {
-                for (int wi = 0; wi < w; ++wi) {
-                    uint32_t v = 0;
-                    if (active) v = g_hist[(size_t)wi * 64 + gbase + origin];
+                for (int w0 = 0; w0 < w; w0 += 8) {
+                    uint32_t v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = (active && w0 + q < w) ? g_hist[(size_t)(w0 + q) * 64 + gbase + origin] : 0u;
                     wave_mem_fence();
-                    if (active) g_hist[(size_t)wi * 64 + lane] = v;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (active && w0 + q < w) g_hist[(size_t)(w0 + q) * 64 + lane] = v[q];
+                    wave_mem_fence();
                 }
             }
             if ((t & 31) != 0 && active) g_hist[(size_t)w * 64 + lane] = hword;
