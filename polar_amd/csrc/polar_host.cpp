@@ -343,7 +343,7 @@ int polar_decode_scl_llr_batch_dev(polar_code_t *h, const double *d_llr, long B,
     const size_t cwords = (h->N >= 128) ? (size_t)(h->N / 32 - 2) : 0;
     if ((rc = h->d_llr_scr.ensure((size_t)grid * big * 64 + 64))) return rc;
     if ((rc = h->d_c_scr.ensure((size_t)grid * 2 * cwords * 64 + 64))) return rc;
-    if ((rc = h->d_hist_scr.ensure((size_t)grid * h->W * 64 + 64))) return rc;
+    if ((rc = h->d_hist_scr.ensure((size_t)grid * 3 * h->W * 64 + 64))) return rc;
     PolarDecodeParams p;
     p.n = h->n; p.N = h->N; p.K = h->K; p.crc = h->crc; p.L = L; p.W = h->W; p.B = B;
     {   // all-frozen prefix [0, P): handled cooperatively by the kernel when one codeword owns 32 lanes

@@ -186,7 +186,9 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     const int cwords = (N >= 128) ? (N / 32 - 2) : 0;                          // words of big C layers (S >= 64)
     uint32_t *g_cl = p.c_scr + (size_t)wave_id * 2 * (size_t)cwords * 64;
     uint32_t *g_cr = g_cl + (size_t)cwords * 64;
-    uint32_t *g_hist = p.hist_scr + (size_t)wave_id * (size_t)p.W * 64;
+    uint32_t *g_hist = p.hist_scr + (size_t)wave_id * 3 * (size_t)p.W * 64;    // decision words [W][64]
+    uint32_t *g_horg = g_hist + (size_t)p.W * 64;                              // link to the previous word's slot
+    uint32_t *g_tb = g_horg + (size_t)p.W * 64;                                // winner's words, per-lane copy
 
     for (long g0 = (long)wave_id * G; g0 < p.B; g0 += (long)nwaves * G) {
         const long cw = g0 + grp;
@@ -775,23 +777,18 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     pm = 0.0;   // killPath zeroes the metric (PolarCode.cpp:293-294)
                 }
                 }   // general path
-                // history flush every 32 unfrozen steps: copy the flushed prefix from `origin`
+                // every 32 unfrozen steps the decision word is stored together with the slot (`origin`) that
+                // holds this path's previous word: a linked list per path, walked once at the end, so that
+                // neither clones nor flushes ever copy history (the reference copies it on every clone,
+                // PolarCode.cpp:574)
                 if ((t & 31) == 31) {
                     const int w = (int)(t >> 5);
-                    if (__any(active && origin != lig)) {
-                        // permuted copy of the flushed words, 8 at a time: all loads of a batch are in flight
-                        // together, then all stores (a word row is read by every lane before any lane writes it)
-                        for (int w0 = 0; w0 < w; w0 += 8) {
-                            uint32_t v[8];
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) v[q] = (active && w0 + q < w) ? g_hist[(size_t)(w0 + q) * 64 + gbase + origin] : 0u;
-                            wave_mem_fence();
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) if (active && w0 + q < w) g_hist[(size_t)(w0 + q) * 64 + lane] = v[q];
-                            wave_mem_fence();
-                        }
+                    if (active) {
+                        g_hist[(size_t)w * 64 + lane] = hword;
+                        g_horg[(size_t)w * 64 + lane] = (uint32_t)origin;
+                        origin = lig;
+                        hword = 0;
                     }
-                    if (active) { g_hist[(size_t)w * 64 + lane] = hword; origin = lig; hword = 0; }
                     wave_mem_fence();
                 }
                 ++t;
@@ -809,32 +806,24 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         }  // phi
         PROF_OUT
 
-        // ---------------- final flush of the decision history ----------------
-        {
-            const int w = (int)(t >> 5);   // complete words
-            if (__any(active && origin != lig)) {
-                for (int w0 = 0; w0 < w; w0 += 8) {
-                    uint32_t v[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = (active && w0 + q < w) ? g_hist[(size_t)(w0 + q) * 64 + gbase + origin] : 0u;
-                    wave_mem_fence();
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) if (active && w0 + q < w) g_hist[(size_t)(w0 + q) * 64 + lane] = v[q];
-                    wave_mem_fence();
-                }
-            }
-            if ((t & 31) != 0 && active) g_hist[(size_t)w * 64 + lane] = hword;
-            wave_mem_fence();
-        }
+        // ---------------- last (partial) history word ----------------
         const int Wused = (int)((t + 31) >> 5);
+        if ((t & 31) != 0 && active) {
+            g_hist[(size_t)(Wused - 1) * 64 + lane] = hword;
+            g_horg[(size_t)(Wused - 1) * 64 + lane] = (uint32_t)origin;
+        }
+        wave_mem_fence();
 
         // ---------------- findMostProbablePath + crc_check: PolarCode.cpp:609-644, 93-108 ----------------
+        // crc_check walks the path's word list backwards: parity of (word & mask_i) per CRC row
         bool pass = true;
         if (p.crc > 0) {
             uint32_t acc = 0;
             if (active) {
-                for (int w = 0; w < Wused; ++w) {
-                    uint32_t hw = g_hist[(size_t)w * 64 + lane];
+                int cur = lig;
+                for (int w = Wused - 1; w >= 0; --w) {
+                    const uint32_t hw = g_hist[(size_t)w * 64 + gbase + cur];
+                    cur = (int)(g_horg[(size_t)w * 64 + gbase + cur] & (GS - 1));
                     for (int i = 0; i < p.crc; ++i)
                         acc ^= (uint32_t)(__popc(hw & p.crc_mask[(size_t)i * p.W + w]) & 1) << i;
                 }
@@ -858,9 +847,20 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
 #ifndef POLAR_PROFILE
             if (p.pm_out && lig == 0) p.pm_out[cw] = pm_win;
 #endif
+        }
+        {   // the winner's words, in order, into this lane's own column of g_tb (every lane of the group walks
+            // the same list, so the loads are broadcasts), then the K info bits by unfrozen rank
+            int cur = win;
+            for (int w = Wused - 1; w >= 0; --w) {
+                g_tb[(size_t)w * 64 + lane] = g_hist[(size_t)w * 64 + gbase + cur];
+                cur = (int)(g_horg[(size_t)w * 64 + gbase + cur] & (GS - 1));   // (stale slots of idle groups stay in range)
+            }
+            wave_mem_fence();
+        }
+        if (valid) {
             for (int b = lig; b < K; b += GS) {
                 unsigned r = p.info_rank[b];
-                uint32_t wd = g_hist[(size_t)(r >> 5) * 64 + gbase + win];
+                uint32_t wd = g_tb[(size_t)(r >> 5) * 64 + lane];
                 p.out[(size_t)cw * K + b] = (uint8_t)((wd >> (r & 31)) & 1u);
             }
         }
