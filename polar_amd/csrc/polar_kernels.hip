@@ -683,18 +683,28 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     // i == lig: my own good fork is never counted against itself (v < mg is false); against my
                     // bad fork the strict part (mg < mb) was counted above, a tie goes to the lower fork index
                     rb += (mg == mb && !goodbit) ? 1 : 0;
-                    u64 m = cbm;
-                    while (m) {
-                        const int i = __builtin_ctzll(m);
-                        m &= m - 1;
-                        const double vb = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mb), i),
-                                                           __builtin_amdgcn_readlane(__double2loint(mb), i));
-                        const int gi = __builtin_amdgcn_readlane((int)goodbit, i);
-                        const int jb = 2 * (i & (GS - 1)) + (gi ? 0 : 1);
-                        const bool same = ((i & ~(GS - 1)) == gbase);
-                        rg += same && ((vb < mg) || (vb == mg && jb < ig));
-                        rb += same && ((vb < mb) || (vb == mb && jb < ib));
+                    // competitive bad forks (few at low SNR, up to all L when garbage paths fill the list):
+                    // same scheme from the second half of the exchange buffer, iterations without a
+                    // competitive bad fork in any group are skipped on the scalar unit
+                    sortbuf[64 + lane] = mb;
+                    wave_mem_fence();
+                    const double *sbb = sortbuf + 64 + gbase;
+                    u64 any_i = 0;                                       // bit i: some group has a competitive bad fork i
+#pragma unroll
+                    for (int g = 0; g < 64 / GS; ++g) any_i |= (cbm >> (g * GS)) & gmask;
+                    for (u64 mi = any_i; mi; mi &= mi - 1) {
+                        const int i = __builtin_ctzll(mi);
+                        const double v = sbb[i];
+                        const u64 mine = __ballot(((cbm >> gbase) >> i) & 1ull);      // lanes whose group's bad fork i competes
+                        const u64 below_me = __ballot(lig > i);
+                        const u64 lt_g = __builtin_amdgcn_fcmp(v, mg, 4), le_g = __builtin_amdgcn_fcmp(v, mg, 5);
+                        const u64 lt_b = __builtin_amdgcn_fcmp(v, mb, 4), le_b = __builtin_amdgcn_fcmp(v, mb, 5);
+                        rg += (int)__builtin_amdgcn_inverse_ballot_w64(((le_g & below_me) | (lt_g & ~below_me)) & mine);
+                        rb += (int)__builtin_amdgcn_inverse_ballot_w64(((le_b & below_me) | (lt_b & ~below_me)) & mine);
                     }
+                    // i == lig: my own bad fork against my good fork: mb < mg cannot hold, a tie goes to the
+                    // lower fork index (the bad fork has the lower index when the good bit is 1)
+                    rg += (cbad && mg == mb && goodbit) ? 1 : 0;
                     if (full) {
                         const bool sg = active && (rg < L);
                         const bool sbd = cbad && (rb < L);

@@ -32,10 +32,8 @@ t = time.perf_counter()
 g.decode_scl_llr_dev(llr.data_ptr(), B, L, out.data_ptr(), prof.data_ptr())
 torch.cuda.synchronize()
 dt = time.perf_counter() - t
-a = prof[:8].cpu().numpy().astype(float)
-names = ["loop ovh", "layer S>SL g (HBM)", "layer S>SL f (HBM)", "layer 4<=S<=SL (LDS)", "layer S<4", "leaf frozen", "leaf unfrozen", "partial sums"]
+a = prof[:16].cpu().numpy().astype(float)
+names = ["loop ovh", "layer S>SL g (HBM)", "layer S>SL f (HBM)", "layer 4<=S<=SL (LDS)", "layer S<4", "leaf frozen / rate-0 block", "leaf unfrozen (rest: flush etc.)", "partial sums", "unf: metric+reduce", "unf: competitive-bad loop", "unf: stack/srcof", "unf: clone shuffles+update", "-", "unf: setup+goods rank loop", "-", "-"]
 print(f"L={L} B={B} time {dt*1e3:.2f} ms -> {B/dt:.0f} cw/s")
-c = prof[8:10].cpu().numpy()
-print(f"  unfrozen steps: fast path {c[0]}, general path {c[1]} (summed over waves)")
 for nm, v in zip(names, a):
     print(f"  {nm:24s} {100*v/a.sum():5.1f}%")
