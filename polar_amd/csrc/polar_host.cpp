@@ -341,6 +341,12 @@ int polar_decode_scl_llr_batch_dev(polar_code_t *h, const double *d_llr, long B,
     const int SL = 1 << lds_log;
     const size_t big = (h->N > 2 * SL) ? (size_t)(h->N - 2 * SL) : 0;
     const size_t cwords = (h->N >= 128) ? (size_t)(h->N / 32 - 2) : 0;
+    {   // the per-wave state scratch is big*512 B per resident wave (1 MiB at N=2048, 16 MiB at N=32768):
+        // cap it at 24 GiB of the 288 GB HBM by running fewer persistent waves for very long codes
+        const size_t per_wave = big * 64 * sizeof(double) + 1;
+        const long cap = (long)((24ull << 30) / per_wave);
+        if (grid > cap) grid = (int)std::max<long>(wpb, (cap / wpb) * wpb);
+    }
     if ((rc = h->d_llr_scr.ensure((size_t)grid * big * 64 + 64))) return rc;
     if ((rc = h->d_c_scr.ensure((size_t)grid * 2 * cwords * 64 + 64))) return rc;
     if ((rc = h->d_hist_scr.ensure((size_t)grid * 3 * h->W * 64 + 64))) return rc;

@@ -210,3 +210,15 @@ def test_winning_path_metric_matches_oracle(built_lib, oracle_built, n, K, crc, 
         bits, want = o.decode_scl_llr_pm(llr[i], L)
         assert (out[i].cpu().numpy() == bits).all()
         assert abs(got[i] - want) <= 1e-10 * max(1.0, abs(want)), (i, got[i], want)
+
+
+@pytest.mark.parametrize("n,K,crc,L,B", [(12, 2048, 16, 8, 24), (13, 4096, 0, 4, 16), (14, 8192, 24, 2, 8),
+                                         (15, 16384, 32, 32, 4), (11, 1024, 32, 64, 12), (7, 100, 7, 16, 64)])
+def test_long_codes_and_extreme_parameters(built_lib, oracle_built, n, K, crc, L, B):
+    """Maximum sizes of the class surface: N up to 32768 (uint16_t block length of the reference),
+    L = 64, crc = 32, K not a power of two."""
+    o, g = _pair(n, K, crc)
+    llr, _ = o.synth_llr(606, 0, B, o.snr_sqrt_linear(1.0))
+    want = o.decode_scl_llr(llr, L)
+    got = g.decode_scl_llr(llr, L)
+    assert (want == got).all()

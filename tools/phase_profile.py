@@ -33,7 +33,7 @@ g.decode_scl_llr_dev(llr.data_ptr(), B, L, out.data_ptr(), prof.data_ptr())
 torch.cuda.synchronize()
 dt = time.perf_counter() - t
 a = prof[:16].cpu().numpy().astype(float)
-names = ["loop ovh", "layer S>SL g (HBM)", "layer S>SL f (HBM)", "layer 4<=S<=SL (LDS)", "layer S<4", "leaf frozen / rate-0 block", "leaf unfrozen (rest: flush etc.)", "partial sums", "unf: metric+reduce", "unf: competitive-bad loop", "unf: stack/srcof", "unf: clone shuffles+update", "-", "unf: setup+goods rank loop", "-", "-"]
+names = ["loop ovh", "layer S>SL g (HBM)", "layer S>SL f (HBM)", "layer 4<=S<=SL (LDS)", "layer S<4", "leaf frozen / rate-0 block", "leaf unfrozen (rest: flush etc.)", "partial sums", "unf: DPP reductions+decision", "unf: competitive-bad loop", "unf: stack/srcof", "unf: clone shuffles+update", "-", "unf: setup+goods rank loop", "unf: wait for leaf (ballot)", "unf: softplus+bounds"]
 print(f"L={L} B={B} time {dt*1e3:.2f} ms -> {B/dt:.0f} cw/s")
 for nm, v in zip(names, a):
     print(f"  {nm:24s} {100*v/a.sum():5.1f}%")
