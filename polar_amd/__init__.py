@@ -116,6 +116,22 @@ class PolarCode:
                                            _p(cm, _u8p) if cm is not None else None, C.byref(h)))
         return cls(num_layers, info_length, float("nan"), crc_size, _handle=h)
 
+    @classmethod
+    def from_construction_file(cls, path, info_length, crc_size=0, crc_matrix=None):
+        """Code from a PolarM Monte-Carlo construction file (PolarM/CodeConstructionData/*.txt: one
+        per-channel error count per line, written at PolarCode.m:120-124). As PolarCode.m:126-135:
+        stable ascending sort of the counts, the first K+crc positions are the unfrozen set and their
+        order is the info-bit order."""
+        counts = np.loadtxt(path).reshape(-1)
+        N = counts.size
+        n = int(round(np.log2(N)))
+        if (1 << n) != N:
+            raise PolarError("construction file must hold a power-of-two number of lines")
+        order = np.argsort(counts, kind="stable").astype(np.uint16)
+        frozen = np.ones(N, np.uint8)
+        frozen[order[: info_length + crc_size]] = 0
+        return cls.from_tables(n, info_length, crc_size, frozen, order, crc_matrix)
+
     def close(self):
         if getattr(self, "_h", None):
             lib().polar_destroy(self._h)

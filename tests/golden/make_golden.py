@@ -109,6 +109,7 @@ def main():
     ref.set_tables(frozen5, order5)
     orc = Oracle(10, 512, 0.5, 0)
     orc.set_tables(frozen5, order5)
+    out[f"{name}/counts"] = counts.astype(np.int32)          # the data file itself (1024 integers), as a fixture
     out[f"{name}/frozen"] = np.packbits(frozen5)
     out[f"{name}/order"] = order5
     out[f"{name}/crcm"] = np.zeros(0, np.uint8)

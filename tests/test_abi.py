@@ -91,3 +91,16 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", ".m")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "liboracle" not in txt and "oracle_lib" not in txt and "polar_oracle" not in txt, f
+
+
+def test_construction_file_loader(built_lib, tmp_path):
+    """PolarM Monte-Carlo construction data (PolarCode.m:111-135): the 16-ASK file's counts are kept
+    as a fixture; loading them from a text file must give the fixture's frozen set and info order."""
+    import polar_amd
+    z, m = G.load()
+    counts = z["cfg5_n10_k512_ask16/counts"]
+    f = tmp_path / "MC_block_length_1024_512_cc.txt"
+    f.write_text("".join(f"{int(c)} \n" for c in counts))       # '%d \n' as PolarCode.m:122
+    g = polar_amd.PolarCode.from_construction_file(str(f), 512)
+    c, frozen, order, crcm = G.tables("cfg5_n10_k512_ask16")
+    assert (g.frozen_bits == frozen).all() and (g.channel_order_descending == order).all()
