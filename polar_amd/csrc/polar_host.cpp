@@ -78,7 +78,7 @@ struct polar_code {
     DevBuf<uint8_t> d_frozen, d_crcm, d_sched;
     DevBuf<uint16_t> d_order, d_info_rank;
     DevBuf<uint32_t> d_crc_mask;
-    DevBuf<double> d_llr_scr, d_tabs;
+    DevBuf<double> d_llr_scr, d_tabs, d_pre;
     DevBuf<uint32_t> d_c_scr, d_hist_scr;
     // staging for the host-pointer entry points
     DevBuf<double> d_in;
@@ -257,7 +257,7 @@ void polar_destroy(polar_code_t *h) {
     if (!h) return;
     if (h->dev_ready) (void)hipSetDevice(h->device);
     h->d_frozen.release(); h->d_sched.release(); h->d_crcm.release(); h->d_order.release(); h->d_info_rank.release();
-    h->d_crc_mask.release(); h->d_tabs.release(); h->d_llr_scr.release(); h->d_c_scr.release(); h->d_hist_scr.release();
+    h->d_crc_mask.release(); h->d_tabs.release(); h->d_pre.release(); h->d_llr_scr.release(); h->d_c_scr.release(); h->d_hist_scr.release();
     h->d_in.release(); h->d_out.release(); h->d_bytes_a.release(); h->d_bytes_b.release();
     h->d_counter.release(); h->d_sel.release();
     delete h;
@@ -356,7 +356,7 @@ int polar_decode_scl_llr_batch_dev(polar_code_t *h, const double *d_llr, long B,
         int P = 0;
         while (P < h->N && h->frozen[P]) ++P;
         int Q = 0;
-        if (gs == 32 && h->prefix_on) {
+        if (gs >= 4 && h->prefix_on) {
             if (P >= 256) Q = 256;
             else { Q = 64; while (Q <= P) Q <<= 1; if (P < 33) Q = 0; }
             if (Q > h->N / 2) Q = 0;
@@ -366,8 +366,14 @@ int polar_decode_scl_llr_batch_dev(polar_code_t *h, const double *d_llr, long B,
     }
     p.llr = d_llr; p.p0 = nullptr; p.out = d_out; p.pm_out = d_pm;
     p.frozen = h->d_frozen.p; p.info_rank = h->d_info_rank.p; p.crc_mask = h->d_crc_mask.p; p.tabs = h->d_tabs.p;
-    p.sched = getenv("POLAR_NO_SCHED") ? nullptr : h->d_sched.p;
+    p.sched = h->d_sched.p;
+    p.pre = nullptr;
+    if (p.prefix_q) {
+        if ((rc = h->d_pre.ensure((size_t)B * (size_t)(h->N - p.prefix_q + 1)))) return rc;
+        p.pre = h->d_pre.p;
+    }
     p.llr_scr = h->d_llr_scr.p; p.c_scr = h->d_c_scr.p; p.hist_scr = h->d_hist_scr.p;
+    if (p.prefix_q) HIP_TRY(polar_launch_prefix(p, (hipStream_t)stream));
     HIP_TRY(polar_launch_decode_llr(p, gs, lds_log, pipe, grid, (hipStream_t)stream));
     return POLAR_OK;
 }
@@ -414,7 +420,7 @@ int polar_decode_scl_p1_batch(polar_code_t *h, const double *p1, const double *p
     HIP_TRY(hipMemcpy(h->d_in.p + (size_t)B * N, p0, (size_t)B * N * sizeof(double), hipMemcpyHostToDevice));
     PolarDecodeParams p;
     p.n = h->n; p.N = N; p.K = h->K; p.crc = h->crc; p.L = L; p.W = h->W; p.B = B;
-    p.prefix_q = 0; p.prefix_len = 0; p.sched = nullptr;
+    p.prefix_q = 0; p.prefix_len = 0; p.sched = nullptr; p.pre = nullptr;
     p.llr = h->d_in.p; p.p0 = h->d_in.p + (size_t)B * N; p.out = h->d_out.p; p.pm_out = nullptr;
     p.frozen = h->d_frozen.p; p.info_rank = h->d_info_rank.p; p.crc_mask = h->d_crc_mask.p; p.tabs = h->d_tabs.p;
     p.llr_scr = h->d_llr_scr.p; p.c_scr = h->d_c_scr.p; p.hist_scr = h->d_hist_scr.p;

@@ -18,6 +18,7 @@ struct PolarDecodeParams {
     const uint16_t *info_rank;   // [K+crc] device: rank of order[beta] among the unfrozen positions
     const uint32_t *crc_mask;    // [crc][W] device: parity masks over unfrozen ranks (check bit included)
     const double *tabs;          // [322] device: T[64] = 2^(-j/64), RC[129] = 1/(1+j/128), LC[129] = log(1+j/128)
+    const double *pre;           // [B][N - Q + 1] device: prefix_kernel output (metric + node-0 f-chain), nullptr if off
     double *llr_scr;             // per-wave scratch: [grid][N - 2*SL][64]
     uint32_t *c_scr;             // per-wave scratch: [grid][2][N/32 - 2][64]
     uint32_t *hist_scr;          // per-wave scratch: [grid][W][64]
@@ -25,6 +26,7 @@ struct PolarDecodeParams {
 
 size_t polar_decode_lds_bytes(int lds_log, int pipe);
 int polar_decode_waves_per_block(int pipe);
+hipError_t polar_launch_prefix(const PolarDecodeParams &p, hipStream_t st);
 hipError_t polar_launch_decode_llr(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, hipStream_t st);
 
 hipError_t polar_launch_decode_p1(const PolarDecodeParams &p, int gs, int grid, hipStream_t st);

@@ -209,91 +209,20 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         unsigned t = 0;                            // unfrozen steps so far (wave-uniform)
         wave_mem_fence();
 
-        // ================= all-frozen prefix, cooperative (GS == 32 only) =================
-        // Until the first unfrozen position only ONE path exists per codeword and every decision is
-        // the frozen 0, so the LLRs of the first Pe leaves form a fixed dataflow of the channel LLRs.
-        // Instead of one lane walking it leaf by leaf (31 idle lanes), the 32 lanes of the group share
-        // the ELEMENTS: (1) the f-chain of the layers above the prefix block (node 0, sizes N/2..Q) is
-        // computed and stored in the standard layout; (2) the block of Q values is expanded by a
-        // log2(Q)-stage f/g butterfly in registers (u = 0 everywhere) into the Q leaf LLRs; (3) the
-        // path metric is accumulated over the leaves in order (same operations, same order as
-        // continuePaths_FrozenBit, PolarCode.cpp:475-487). The sequential walk resumes at phi = Pe.
+        // ================= all-frozen prefix (computed by prefix_kernel) =================
+        // Until the first unfrozen position only ONE path exists per codeword and every decision is the
+        // frozen 0: prefix_kernel has already produced, per codeword, the f-chain of the layers above
+        // the prefix block (node 0, sizes N/2..Q, contiguous in p.pre) and the path metric of the first
+        // Pe leaves. The walk resumes at phi = Pe; a layer of size 2S >= Q is read from that buffer
+        // (same addresses for every path of the codeword: broadcast) until its first rewrite at phi = 2S.
         int phi_start = 0, forced_top = 0;
-        if (GS == 32 && p.prefix_q > 0) {
+        const double *pre_cw = nullptr;
+        if (p.prefix_q > 0) {
             const int Q = p.prefix_q, Pe = p.prefix_len;
-            const int R = Q >> 5;                              // values per lane (2..8)
-            const int own = gbase + L - 1;                     // slot of the single active path
-            double x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (valid) {
-                for (int S = N / 2; S >= Q; S >>= 1) {         // layers above the block: node 0, f of the layer above
-                    const bool from_ch = (2 * S == N);
-                    const double *inp = from_ch ? nullptr : ((2 * S <= SL) ? lds_llr + (size_t)(2 * S - 1) * 64 + own
-                                                                          : g_llr + (size_t)(2 * S - 2 * SL) * 64 + own);
-                    double *outp = (S <= SL) ? lds_llr + (size_t)(S - 1) * 64 + own : g_llr + (size_t)(S - 2 * SL) * 64 + own;
-                    for (int j = lig; j < S; j += 32) {
-                        double a, b;
-                        if (from_ch) {
-                            unsigned idx = __brev((unsigned)j) >> (32 - n);
-                            a = in0[idx]; b = in0[idx + 1];
-                        } else {
-                            a = inp[(size_t)j * 64]; b = inp[(size_t)(j + S) * 64];
-                        }
-                        const double r = f_node(a, b, tb);
-                        outp[(size_t)j * 64] = r;
-                        if (S == Q) {
-#pragma unroll
-                            for (int rr = 0; rr < 8; ++rr) if (rr == (j >> 5)) x[rr] = r;
-                        }
-                    }
-                    wave_mem_fence();
-                }
-            } else {
-                for (int S = N / 2; S >= Q; S >>= 1) wave_mem_fence();
-            }
-            // butterfly: stage with half-size h turns every node of size 2h into its f-child (lower
-            // half) and g-child (upper half, u = 0); value index i = r*32 + lig
-            for (int h = Q / 2; h >= 1; h >>= 1) {
-                if (h >= 32) {
-                    const int hr = h >> 5;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        if (r < R && (r & hr) == 0) {
-#pragma unroll
-                            for (int r2 = 0; r2 < 8; ++r2) {
-                                if (r2 == r + hr) {
-                                    const double lo = x[r], hi = x[r2];
-                                    x[r] = f_node(lo, hi, tb);
-                                    x[r2] = g_node(lo, hi, 0u);
-                                }
-                            }
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        if (r < R) {
-                            const double mine = x[r];
-                            const double other = shfl_d(mine, lane ^ h);
-                            x[r] = (lig & h) ? g_node(other, mine, 0u) : f_node(mine, other, tb);
-                        }
-                    }
-                }
-            }
-            // path metric over the leaves 0..Pe-1 in order (leaf phi sits in x[phi>>5] of lane phi&31)
-            double acc = 0.0;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                if (r < R && r * 32 < Pe) {
-                    const double spv = softplus_ref(-x[r], tb);
-                    const int cnt = (Pe - r * 32 < 32) ? (Pe - r * 32) : 32;
-                    for (int c = 0; c < cnt; ++c) acc += shfl_d(spv, gbase + c);
-                }
-            }
+            pre_cw = p.pre + (size_t)(valid ? cw : 0) * (size_t)(N - Q + 1);
             if (active) {
-                pm = acc;
-                // state the sequential walk expects: slot pointers of the stored layers, zero partial
-                // sums of every completed (all-frozen) left subtree
-                for (int S = N / 2; S >= Q; S >>= 1) pL.set(__builtin_ctz((unsigned)S), lig);
+                pm = pre_cw[0];
+                // zero partial sums of every completed (all-frozen) left subtree
                 for (int S = 64; S <= Q && S <= N / 2; S <<= 1) {
                     uint32_t *cz = g_cl + (size_t)(S / 32 - 2) * 64 + lane;
                     for (int w = 0; w < S / 32; ++w) cz[(size_t)w * 64] = 0u;
@@ -369,8 +298,11 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     const int H = S / 2;
                     if (active) {
                         const bool in_is_ch = (lam == 1);
-                        const int pin = in_is_ch ? 0 : pL.get(sh + 1);
-                        const double *inp = in_is_ch ? nullptr : (g_llr + (size_t)(2 * S - 2 * SL) * 64 + gbase + pin);
+                        const bool in_pre = !in_is_ch && pre_cw && 2 * S >= p.prefix_q && phi < 2 * S;
+                        const int pin = (in_is_ch || in_pre) ? 0 : pL.get(sh + 1);
+                        const size_t istr = in_pre ? 1 : 64;      // prefix layers are contiguous per codeword
+                        const double *inp = in_is_ch ? nullptr : (in_pre ? pre_cw + 1 + (size_t)(N - 4 * S)
+                                                                         : g_llr + (size_t)(2 * S - 2 * SL) * 64 + gbase + pin);
                         double *out0 = (S <= SL) ? (lds_llr + (size_t)(S - 1) * 64 + lane) : (g_llr + (size_t)(S - 2 * SL) * 64 + lane);
                         double *out1 = (H <= SL) ? (lds_llr + (size_t)(H - 1) * 64 + lane) : (g_llr + (size_t)(H - 2 * SL) * 64 + lane);
                         uint32_t cb0 = 0, cb1 = 0;          // partial-sum bits for elements j.. and j+H..
@@ -392,10 +324,10 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                             } else {
 #pragma unroll
                                 for (int k = 0; k < FU; ++k) {
-                                    a0[k] = inp[(size_t)(j + k) * 64];
-                                    b0[k] = inp[(size_t)(j + k + S) * 64];
-                                    a1[k] = inp[(size_t)(j + k + H) * 64];
-                                    b1[k] = inp[(size_t)(j + k + H + S) * 64];
+                                    a0[k] = inp[(size_t)(j + k) * istr];
+                                    b0[k] = inp[(size_t)(j + k + S) * istr];
+                                    a1[k] = inp[(size_t)(j + k + H) * istr];
+                                    b1[k] = inp[(size_t)(j + k + H + S) * istr];
                                 }
                             }
                             if (odd && S > 32 && (j & 31) == 0) {
@@ -433,11 +365,13 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     const double *inp;   // element j at inp[j*istride]
                     size_t istride;
                     const bool in_is_ch = (lam == 1);
-                    const bool in_lds = (!in_is_ch) && (2 * S <= SL);
-                    if (in_lds) inp = lds_llr + (size_t)(2 * S - 1) * 64 + gbase + pin;
+                    const bool in_pre = !in_is_ch && pre_cw && 2 * S >= p.prefix_q && phi < 2 * S;
+                    const bool in_lds = (!in_is_ch) && !in_pre && (2 * S <= SL);
+                    istride = 64;
+                    if (in_pre) { inp = pre_cw + 1 + (size_t)(N - 4 * S); istride = 1; }
+                    else if (in_lds) inp = lds_llr + (size_t)(2 * S - 1) * 64 + gbase + pin;
                     else if (!in_is_ch) inp = g_llr + (size_t)(2 * S - 2 * SL) * 64 + gbase + pin;
                     else inp = nullptr;
-                    istride = 64;
                     const bool out_lds = (S <= SL);
                     double *outp = out_lds ? (lds_llr + (size_t)(S - 1) * 64 + lane)
                                            : (g_llr + (size_t)(S - 2 * SL) * 64 + lane);
@@ -465,8 +399,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                             } else {
 #pragma unroll
                                 for (int k = 0; k < U; ++k) {
-                                    a[k] = inp[(size_t)(j + k) * 64];
-                                    b[k] = inp[(size_t)(j + k + S) * 64];
+                                    a[k] = inp[(size_t)(j + k) * istride];
+                                    b[k] = inp[(size_t)(j + k + S) * istride];
                                 }
                             }
                         };
@@ -660,10 +594,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     const bool goodbit = (leaf < 0);                       // bit the leaf LLR favours
                     const double mg = goodbit ? -pf1 : -pf0;                // PM of my good / bad fork
                     const double mb = goodbit ? -pf0 : -pf1;
-                    const int ig = 2 * lig + (goodbit ? 1 : 0), ib = 2 * lig + (goodbit ? 0 : 1);
                     const bool cbad = active && full && !(bl > gmax);
                     const u64 cbm = __ballot(cbad);
-                    const u64 gbits = __ballot(goodbit) >> gbase;
                     sortbuf[lane] = mg;
                     wave_mem_fence();
                     int rg = 0, rb = 0;
@@ -876,6 +808,107 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         }
         wave_mem_fence();
     }  // codeword groups
+}
+
+// ------------------------------------------------------------------------------------------
+// prefix_kernel — the all-frozen prefix [0, Pe) of every codeword, 32 lanes per codeword.
+// Until the first unfrozen position one path exists and every decision is the frozen 0, so the leaf
+// LLRs of the prefix are a fixed f/g dataflow of the channel LLRs (g with u = 0). The 32 lanes share
+// the ELEMENTS: (1) f-chain of the layers above the prefix block (node 0 of the layers of size
+// N/2 .. Q), written contiguously per codeword (pre[cw][1 + N - 2S + j]) for the decode kernel to
+// read; (2) the Q block values expanded in registers by a log2(Q)-stage butterfly into the Q leaf
+// LLRs; (3) the path metric accumulated over the first Pe leaves in order, same operations and order
+// as continuePaths_FrozenBit (PolarCode.cpp:475-487) -> pre[cw][0].
+__global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p) {
+    __shared__ double tabs[324];
+    for (int i = threadIdx.x; i < 322; i += 256) tabs[i] = p.tabs[i];
+    __syncthreads();
+    const Tabs tb = {tabs, tabs + 64, tabs + 64 + 129};
+    const int lane = threadIdx.x & 63, lig = lane & 31, gbase = lane & 32;
+    const int n = p.n, N = p.N, Q = p.prefix_q, Pe = p.prefix_len;
+    const int R = Q >> 5;
+    const long per_block = 8;
+    for (long c0 = (long)blockIdx.x * per_block; c0 < p.B; c0 += (long)gridDim.x * per_block) {
+        const long cw = c0 + (threadIdx.x >> 5);
+        const bool valid = cw < p.B;
+        const double *in0 = p.llr + (size_t)(valid ? cw : 0) * N;
+        double *pre = const_cast<double *>(p.pre) + (size_t)(valid ? cw : 0) * (size_t)(N - Q + 1);
+        double x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int S = N / 2; S >= Q; S >>= 1) {
+            if (valid) {
+                const bool from_ch = (2 * S == N);
+                const double *inp = pre + 1 + (size_t)(N - 4 * S);      // layer of size 2S (unused when from_ch)
+                double *outp = pre + 1 + (size_t)(N - 2 * S);
+                for (int j = lig; j < S; j += 32) {
+                    double a, b;
+                    if (from_ch) {
+                        unsigned idx = __brev((unsigned)j) >> (32 - n);
+                        a = in0[idx]; b = in0[idx + 1];
+                    } else {
+                        a = inp[j]; b = inp[j + S];
+                    }
+                    const double r = f_node(a, b, tb);
+                    outp[j] = r;
+                    if (S == Q) {
+#pragma unroll
+                        for (int rr = 0; rr < 8; ++rr) if (rr == (j >> 5)) x[rr] = r;
+                    }
+                }
+            }
+            wave_mem_fence();
+        }
+        // butterfly: a stage with half-size h turns every node of size 2h into its f-child (lower half)
+        // and its g-child (upper half, u = 0); value index i = r*32 + lig
+        for (int h = Q / 2; h >= 1; h >>= 1) {
+            if (h >= 32) {
+                const int hr = h >> 5;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    if (r < R && (r & hr) == 0) {
+#pragma unroll
+                        for (int r2 = 0; r2 < 8; ++r2) {
+                            if (r2 == r + hr) {
+                                const double lo = x[r], hi = x[r2];
+                                x[r] = f_node(lo, hi, tb);
+                                x[r2] = g_node(lo, hi, 0u);
+                            }
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    if (r < R) {
+                        const double mine = x[r];
+                        const double other = shfl_d(mine, lane ^ h);
+                        x[r] = (lig & h) ? g_node(other, mine, 0u) : f_node(mine, other, tb);
+                    }
+                }
+            }
+        }
+        // path metric over the leaves 0..Pe-1 in order (leaf phi sits in x[phi>>5] of lane phi&31)
+        double acc = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (r < R && r * 32 < Pe) {
+                const double al = fabs(x[r]);
+                double sneg, spos;
+                softplus_pair(al, false, tb, sneg, spos);
+                const double spv = (x[r] < 0) ? spos : sneg;
+                const int cnt = (Pe - r * 32 < 32) ? (Pe - r * 32) : 32;
+                for (int c = 0; c < cnt; ++c) acc += shfl_d(spv, gbase + c);
+            }
+        }
+        if (valid && lig == 0) pre[0] = acc;
+        wave_mem_fence();
+    }
+}
+
+hipError_t polar_launch_prefix(const PolarDecodeParams &p, hipStream_t st) {
+    long blocks = (p.B + 7) / 8;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(prefix_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
