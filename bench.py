@@ -88,12 +88,16 @@ def main():
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
+    for a, b_ in ev:            # create the underlying hipEvent_t handles
+        a.record(); b_.record()
+
     def step(i=None):
+        # HIP events are recorded by the library on the launch stream right around the dominant
+        # kernel (scl_decode_llr_kernel), after the small prefix kernel
         if i is not None:
-            ev[i][0].record()
-        code.decode_scl_llr_dev(llr.data_ptr(), B, L, out.data_ptr())
-        if i is not None:
-            ev[i][1].record()
+            code.decode_scl_llr_dev(llr.data_ptr(), B, L, out.data_ptr(), ev_start=ev[i][0].cuda_event, ev_stop=ev[i][1].cuda_event)
+        else:
+            code.decode_scl_llr_dev(llr.data_ptr(), B, L, out.data_ptr())
         code.count_errors_dev(out.data_ptr(), sent.data_ptr(), B, counters.data_ptr())
         counters[1] += B
 

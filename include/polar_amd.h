@@ -84,6 +84,11 @@ int polar_decode_scl_llr_batch(polar_code_t *h, const double *llr, long B, int L
  * d_pm (optional, may be NULL) receives the winning path metric per codeword. */
 int polar_decode_scl_llr_batch_dev(polar_code_t *h, const double *d_llr, long B, int L, uint8_t *d_out,
                                    double *d_pm, void *stream);
+/* same, recording two hipEvent_t (may be NULL) on `stream` immediately around the launch of the
+ * dominant kernel (scl_decode_llr_kernel), i.e. after the small all-frozen-prefix kernel — for
+ * bench.py's roofline line */
+int polar_decode_scl_llr_batch_dev_ev(polar_code_t *h, const double *d_llr, long B, int L, uint8_t *d_out,
+                                      double *d_pm, void *stream, void *ev_start, void *ev_stop);
 
 /* ---- PolarCode::decode_scl_p1 (PolarCode.cpp:110-128; PolarCode.m:299-310) ---- */
 int polar_decode_scl_p1(polar_code_t *h, const double *p1 /*[N]*/, const double *p0 /*[N]*/, int L, uint8_t *out /*[K]*/);

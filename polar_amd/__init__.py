@@ -229,9 +229,12 @@ class PolarCode:
     decode_SC_P1 = decode_sc_p1
 
     # ---- device-resident entry points (torch tensors are only memory + stream plumbing) ---
-    def decode_scl_llr_dev(self, llr_ptr, B, list_size, out_ptr, pm_ptr=0, stream=None):
-        _check(lib().polar_decode_scl_llr_batch_dev(self._h, C.c_void_p(llr_ptr), C.c_long(B), C.c_int(list_size),
-                                                    C.c_void_p(out_ptr), C.c_void_p(pm_ptr), _stream_ptr(stream)))
+    def decode_scl_llr_dev(self, llr_ptr, B, list_size, out_ptr, pm_ptr=0, stream=None, ev_start=0, ev_stop=0):
+        """ev_start / ev_stop: raw hipEvent_t handles (e.g. torch.cuda.Event(...).cuda_event) recorded
+        immediately around the dominant kernel's launch."""
+        _check(lib().polar_decode_scl_llr_batch_dev_ev(self._h, C.c_void_p(llr_ptr), C.c_long(B), C.c_int(list_size),
+                                                       C.c_void_p(out_ptr), C.c_void_p(pm_ptr), _stream_ptr(stream),
+                                                       C.c_void_p(ev_start), C.c_void_p(ev_stop)))
 
     def synth_llr_dev(self, seed, trial0, B, s, llr_ptr, info_ptr=0, stream=None):
         _check(lib().polar_synth_llr_dev(self._h, C.c_uint64(seed), C.c_uint64(trial0), C.c_long(B), C.c_double(s),

@@ -316,6 +316,11 @@ double polar_snr_sqrt_linear(const polar_code_t *h, double ebno_db) {   // Polar
 // ------------------------------------------------------------------------------------------
 int polar_decode_scl_llr_batch_dev(polar_code_t *h, const double *d_llr, long B, int L, uint8_t *d_out,
                                    double *d_pm, void *stream) {
+    return polar_decode_scl_llr_batch_dev_ev(h, d_llr, B, L, d_out, d_pm, stream, nullptr, nullptr);
+}
+
+int polar_decode_scl_llr_batch_dev_ev(polar_code_t *h, const double *d_llr, long B, int L, uint8_t *d_out,
+                                      double *d_pm, void *stream, void *ev_start, void *ev_stop) {
     if (!h || !d_llr || !d_out) return fail(POLAR_E_ARG, "NULL argument");
     if (L < 1 || L > POLAR_MAX_LIST) return fail(POLAR_E_ARG, "list size %d out of range [1, %d]", L, POLAR_MAX_LIST);
     if (B < 0) return fail(POLAR_E_ARG, "negative batch");
@@ -374,7 +379,9 @@ int polar_decode_scl_llr_batch_dev(polar_code_t *h, const double *d_llr, long B,
     }
     p.llr_scr = h->d_llr_scr.p; p.c_scr = h->d_c_scr.p; p.hist_scr = h->d_hist_scr.p;
     if (p.prefix_q) HIP_TRY(polar_launch_prefix(p, (hipStream_t)stream));
+    if (ev_start) HIP_TRY(hipEventRecord((hipEvent_t)ev_start, (hipStream_t)stream));
     HIP_TRY(polar_launch_decode_llr(p, gs, lds_log, pipe, grid, (hipStream_t)stream));
+    if (ev_stop) HIP_TRY(hipEventRecord((hipEvent_t)ev_stop, (hipStream_t)stream));
     return POLAR_OK;
 }
 
