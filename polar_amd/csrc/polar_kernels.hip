@@ -95,6 +95,7 @@ __device__ __forceinline__ double f_node(double a, double b, const Tabs &tb) {
     const double fa = fabs(a), fb = fabs(b);
     const double mx = (fa < fb) ? fb : fa;
     const double mn = (fb < fa) ? fb : fa;
+#ifndef POLAR_EXPERIMENT_NO_EXACT_F   // (measurement-only build: how much VALU work is NOT the exact f-node)
     if (40 > mx) {
         // |f| <= min(|a|,|b|): when that is within a few orders of the rounding noise (1e-16) the
         // reference's result IS its rounding noise (e.g. exactly 0 once e^a, e^b round to 1), so the
@@ -103,8 +104,14 @@ __device__ __forceinline__ double f_node(double a, double b, const Tabs &tb) {
         const double base = ((a < 0) != (b < 0)) ? -mn : mn;
         return base + (h_fn(fabs(a + b), tb) - h_fn(fabs(a - b), tb));
     }
-    const double sg = (double)((a < 0) ? -1 : (a > 0)) * ((b < 0) ? -1 : (b > 0));
-    return sg * mn;
+#endif
+    // min-sum branch, PolarCode.cpp:443-445: sgn(a)*sgn(b)*min(|a|,|b|) with sgn(0) = 0. The product
+    // of two signs in {-1,0,1} times a magnitude is that magnitude with the XOR of the sign bits, or
+    // +0 when an operand is zero — done on the high words instead of two int->double conversions
+    // and two multiplies.
+    const int sx = (__double2hiint(a) ^ __double2hiint(b)) & (int)0x80000000;
+    const double r = __hiloint2double(__double2hiint(mn) | sx, __double2loint(mn));
+    return (mn == 0.0) ? 0.0 : r;
 }
 // g-node: PolarCode.cpp:449-450  (1 - 2u)*a + b
 __device__ __forceinline__ double g_node(double a, double b, unsigned u) {
