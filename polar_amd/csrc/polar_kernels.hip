@@ -25,6 +25,7 @@
 // (PolarCode.cpp:437-451, 483, 505-506); build with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "polar_kernels.h"
 #include "polar_device.h"
@@ -308,62 +309,97 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                         const bool in_pre = !in_is_ch && pre_cw && 2 * S >= p.prefix_q && phi < 2 * S;
                         const int pin = (in_is_ch || in_pre) ? 0 : pL.get(sh + 1);
                         const size_t istr = in_pre ? 1 : 64;      // prefix layers are contiguous per codeword
-                        const double *inp = in_is_ch ? nullptr : (in_pre ? pre_cw + 1 + (size_t)(N - 4 * S)
+                        const double *gin = in_is_ch ? nullptr : (in_pre ? pre_cw + 1 + (size_t)(N - 4 * S)
                                                                          : g_llr + (size_t)(2 * S - 2 * SL) * 64 + gbase + pin);
-                        double *out0 = (S <= SL) ? (lds_llr + (size_t)(S - 1) * 64 + lane) : (g_llr + (size_t)(S - 2 * SL) * 64 + lane);
-                        double *out1 = (H <= SL) ? (lds_llr + (size_t)(H - 1) * 64 + lane) : (g_llr + (size_t)(H - 2 * SL) * 64 + lane);
                         uint32_t cb0 = 0, cb1 = 0;          // partial-sum bits for elements j.. and j+H..
                         const uint32_t *cwp = nullptr;
                         if (odd) {
                             if (S <= 32) { cb0 = (uint32_t)(clsmall >> S); cb1 = cb0 >> H; }
                             else cwp = g_cl + (size_t)(S / 32 - 2) * 64 + gbase + pC.get(sh);
                         }
-                        for (int j = 0; j < H; j += FU) {
-                            double a0[FU], b0[FU], a1[FU], b1[FU];
-                            if (in_is_ch) {
+                        // the body is instantiated once per address-space combination of its outputs: a pointer
+                        // that may be LDS or global degrades every access to a FLAT instruction, which waits on
+                        // vmcnt AND lgkmcnt (i.e. for every outstanding HBM store) before a dependent use
+                        auto fused_body = [&](const double *inp, double *out0, double *out1) {
+                            for (int j = 0; j < H; j += FU) {
+                                double a0[FU], b0[FU], a1[FU], b1[FU];
+                                if (in_is_ch) {
 #pragma unroll
-                                for (int k = 0; k < FU; ++k) {
-                                    unsigned i0 = __brev((unsigned)(j + k)) >> (32 - n);
-                                    unsigned i1 = __brev((unsigned)(j + k + H)) >> (32 - n);
-                                    a0[k] = in0[i0]; b0[k] = in0[i0 + 1];
-                                    a1[k] = in0[i1]; b1[k] = in0[i1 + 1];
-                                }
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < FU; ++k) {
-                                    a0[k] = inp[(size_t)(j + k) * istr];
-                                    b0[k] = inp[(size_t)(j + k + S) * istr];
-                                    a1[k] = inp[(size_t)(j + k + H) * istr];
-                                    b1[k] = inp[(size_t)(j + k + H + S) * istr];
-                                }
-                            }
-                            if (odd && S > 32 && (j & 31) == 0) {
-                                cb0 = cwp[(size_t)(j >> 5) * 64];
-                                cb1 = (H >= 32) ? cwp[(size_t)((j + H) >> 5) * 64] : (cb0 >> H);
-                            }
-                            // element by element: (x0, x1) of layer lam -> stored -> y of layer lam+1 -> stored
-#pragma unroll
-                            for (int k = 0; k < FU; ++k) {
-                                double x0, x1;
-                                if (odd) {
-                                    const int bi = (S > 32) ? ((j + k) & 31) : (j + k);
-                                    x0 = g_node(a0[k], b0[k], (cb0 >> bi) & 1u);
-                                    x1 = g_node(a1[k], b1[k], (cb1 >> bi) & 1u);
+                                    for (int k = 0; k < FU; ++k) {
+                                        unsigned i0 = __brev((unsigned)(j + k)) >> (32 - n);
+                                        unsigned i1 = __brev((unsigned)(j + k + H)) >> (32 - n);
+                                        a0[k] = in0[i0]; b0[k] = in0[i0 + 1];
+                                        a1[k] = in0[i1]; b1[k] = in0[i1 + 1];
+                                    }
                                 } else {
-                                    x0 = f_node(a0[k], b0[k], tb);
-                                    x1 = f_node(a1[k], b1[k], tb);
+#pragma unroll
+                                    for (int k = 0; k < FU; ++k) {
+                                        a0[k] = inp[(size_t)(j + k) * istr];
+                                        b0[k] = inp[(size_t)(j + k + S) * istr];
+                                        a1[k] = inp[(size_t)(j + k + H) * istr];
+                                        b1[k] = inp[(size_t)(j + k + H + S) * istr];
+                                    }
                                 }
-                                out0[(size_t)(j + k) * 64] = x0;
-                                out0[(size_t)(j + k + H) * 64] = x1;
-                                out1[(size_t)(j + k) * 64] = f_node(x0, x1, tb);
+                                if (odd && S > 32 && (j & 31) == 0) {
+                                    cb0 = cwp[(size_t)(j >> 5) * 64];
+                                    cb1 = (H >= 32) ? cwp[(size_t)((j + H) >> 5) * 64] : (cb0 >> H);
+                                }
+                                // element by element: (x0, x1) of layer lam -> stored -> y of layer lam+1 -> stored
+#pragma unroll
+                                for (int k = 0; k < FU; ++k) {
+                                    double x0, x1;
+                                    if (odd) {
+                                        const int bi = (S > 32) ? ((j + k) & 31) : (j + k);
+                                        x0 = g_node(a0[k], b0[k], (cb0 >> bi) & 1u);
+                                        x1 = g_node(a1[k], b1[k], (cb1 >> bi) & 1u);
+                                    } else {
+                                        x0 = f_node(a0[k], b0[k], tb);
+                                        x1 = f_node(a1[k], b1[k], tb);
+                                    }
+                                    out0[(size_t)(j + k) * 64] = x0;
+                                    out0[(size_t)(j + k + H) * 64] = x1;
+                                    out1[(size_t)(j + k) * 64] = f_node(x0, x1, tb);
+                                }
                             }
-                        }
+                        };
+                        if (S <= SL) fused_body(gin, lds_llr + (size_t)(S - 1) * 64 + lane, lds_llr + (size_t)(H - 1) * 64 + lane);
+                        else if (H <= SL) fused_body(gin, g_llr + (size_t)(S - 2 * SL) * 64 + lane, lds_llr + (size_t)(H - 1) * 64 + lane);
+                        else fused_body(gin, g_llr + (size_t)(S - 2 * SL) * 64 + lane, g_llr + (size_t)(H - 2 * SL) * 64 + lane);
                         pL.set(sh, lig);
                         pL.set(sh - 1, lig);
                     }
                     wave_mem_fence();
                     PROF(odd ? 1 : 2)
                     ++lam;          // layer lam+1 is done
+                    continue;
+                }
+                // ---- both layers in LDS (the bottom of the tree, visited at almost every leaf): plain ds_read /
+                // ds_write on provably-LDS pointers, all inputs of the visit loaded before the first f
+                if (lam > 1 && 2 * S <= SL) {
+                    if (active) {
+                        const double *li = lds_llr + (size_t)(2 * S - 1) * 64 + gbase + pL.get(sh + 1);
+                        double *lo = lds_llr + (size_t)(S - 1) * 64 + lane;
+                        const uint32_t cb = odd ? (uint32_t)(clsmall >> S) : 0u;
+                        auto small = [&](auto SS) {
+                            constexpr int S_ = decltype(SS)::value;
+                            double a[S_], b[S_], r[S_];
+#pragma unroll
+                            for (int j = 0; j < S_; ++j) { a[j] = li[(size_t)j * 64]; b[j] = li[(size_t)(j + S_) * 64]; }
+#pragma unroll
+                            for (int j = 0; j < S_; ++j) r[j] = odd ? g_node(a[j], b[j], (cb >> j) & 1u) : f_node(a[j], b[j], tb);
+#pragma unroll
+                            for (int j = 0; j < S_; ++j) lo[(size_t)j * 64] = r[j];
+                            leaf = r[S_ - 1];
+                        };
+                        if (S == 1) small(std::integral_constant<int, 1>{});
+                        else if (S == 2) small(std::integral_constant<int, 2>{});
+                        else if (S == 4) small(std::integral_constant<int, 4>{});
+                        else if (S == 8) small(std::integral_constant<int, 8>{});
+                        else small(std::integral_constant<int, 16>{});      // (lds_log = 5)
+                        pL.set(sh, lig);
+                    }
+                    wave_mem_fence();
+                    PROF(S >= 4 ? 3 : 4)
                     continue;
                 }
                 if (active) {
@@ -373,15 +409,13 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     size_t istride;
                     const bool in_is_ch = (lam == 1);
                     const bool in_pre = !in_is_ch && pre_cw && 2 * S >= p.prefix_q && phi < 2 * S;
-                    const bool in_lds = (!in_is_ch) && !in_pre && (2 * S <= SL);
+                    constexpr bool in_lds = false;          // (LDS inputs were handled above)
                     istride = 64;
                     if (in_pre) { inp = pre_cw + 1 + (size_t)(N - 4 * S); istride = 1; }
-                    else if (in_lds) inp = lds_llr + (size_t)(2 * S - 1) * 64 + gbase + pin;
                     else if (!in_is_ch) inp = g_llr + (size_t)(2 * S - 2 * SL) * 64 + gbase + pin;
                     else inp = nullptr;
                     const bool out_lds = (S <= SL);
-                    double *outp = out_lds ? (lds_llr + (size_t)(S - 1) * 64 + lane)
-                                           : (g_llr + (size_t)(S - 2 * SL) * 64 + lane);
+                    auto generic_body = [&](double *outp) {
                     // partial sums for g (column 0 of C_lam)
                     uint32_t cbits = 0;
                     const uint32_t *cwp = nullptr;
@@ -475,6 +509,9 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                             leaf = r;
                         }
                     }
+                    };
+                    if (out_lds) generic_body(lds_llr + (size_t)(S - 1) * 64 + lane);
+                    else generic_body(g_llr + (size_t)(S - 2 * SL) * 64 + lane);
                     pL.set(sh, lig);
                 }
                 wave_mem_fence();
