@@ -17,7 +17,7 @@ except Exception:  # pragma: no cover - torch is plumbing; the library also work
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpolar_amd.so")
+LIB_PATH = os.environ.get("POLAR_AMD_LIB") or os.path.join(_HERE, "libpolar_amd.so")   # (override: A/B builds)
 
 _dp = C.POINTER(C.c_double)
 _u8p = C.POINTER(C.c_uint8)

@@ -50,6 +50,9 @@ def build(force=False, verbose=False, profile=False):
     os.makedirs(BUILD, exist_ok=True)
     lib_out = os.path.join(HERE, "libpolar_amd_prof.so") if profile else LIB
     tag = ".prof" if profile else ""
+    if os.environ.get("POLAR_BUILD_TAG"):          # A/B experiments: separate objects and library
+        tag = "." + os.environ["POLAR_BUILD_TAG"]
+        lib_out = os.path.join(HERE, "libpolar_amd_%s.so" % os.environ["POLAR_BUILD_TAG"])
     headers = [os.path.join(INC, f) for f in os.listdir(INC)] + \
               [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     objs = []

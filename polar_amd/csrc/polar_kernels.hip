@@ -116,7 +116,9 @@ __device__ __forceinline__ double f_node(double a, double b, const Tabs &tb) {
 }
 // g-node: PolarCode.cpp:449-450  (1 - 2u)*a + b
 __device__ __forceinline__ double g_node(double a, double b, unsigned u) {
-    return (double)(1 - 2 * (int)u) * a + b;
+    // (1 - 2u) is +1 or -1 and the product with it is exact: flip the sign bit of a, then add
+    const double sa = __hiloint2double(__double2hiint(a) ^ (int)(u << 31), __double2loint(a));
+    return sa + b;
 }
 // log(1 + exp(x)) of PolarCode.cpp:483,505-506: +inf for x > 709.78 (fp64 exp overflow), exactly
 // 0 for x <= -36.74
