@@ -120,18 +120,10 @@ __device__ __forceinline__ double g_node(double a, double b, unsigned u) {
     const double sa = __hiloint2double(__double2hiint(a) ^ (int)(u << 31), __double2loint(a));
     return sa + b;
 }
-// log(1 + exp(x)) of PolarCode.cpp:483,505-506: +inf for x > 709.78 (fp64 exp overflow), exactly
-// 0 for x <= -36.74
-__device__ __forceinline__ double softplus_ref(double x, const Tabs &tb) {
-    if (x > 709.782712893384) return __builtin_inf();
-    if (fabs(x) < 9.5367431640625e-07) return softplus_literal(x);   // noise regime: literal (see f_node)
-    const double hx = h_fn(fabs(x), tb);
-    return (x > 0) ? x + hx : hx;
-}
-
-// log(1+e^-a) and log(1+e^a) for a = |llr| >= 0 with ONE h evaluation; `skip` (wave-uniform: every
-// lane has a >= 37) avoids the transcendental altogether: log(1+e^-a) is exactly 0 there and
-// a + 0 = a (softplus_ref above), +inf beyond the fp64 exp overflow point.
+// The path-metric terms log(1 + exp(-+llr)) of PolarCode.cpp:483,505-506 for a = |llr| >= 0, with ONE
+// h evaluation: log(1+e^-a) = h(a) (exactly 0 for a >= 36.74, where the reference's 1+e^-a rounds to
+// 1), log(1+e^a) = a + h(a) (+inf beyond the fp64 exp overflow point 709.78, as the reference).
+// `skip` (wave-uniform: every lane has a >= 37) avoids the transcendental altogether.
 __device__ __forceinline__ void softplus_pair(double a, bool skip, const Tabs &tb, double &sneg, double &spos) {
     double hx = 0.0;
     if (!skip) {
