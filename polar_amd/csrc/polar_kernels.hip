@@ -31,12 +31,14 @@
 #include "polar_device.h"
 
 #ifdef POLAR_PROFILE
-#define PROF_DECL u64 prof_acc[8] = {0,0,0,0,0,0,0,0}; u64 prof_t = __builtin_readcyclecounter();
+#define PROF_DECL u64 prof_acc[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; u64 prof_t = __builtin_readcyclecounter();
 #define PROF(i) { u64 t_ = __builtin_readcyclecounter(); prof_acc[i] += t_ - prof_t; prof_t = t_; }
-#define PROF_OUT if (lane == 0 && p.pm_out) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd((u64 *)p.pm_out + i_, prof_acc[i_]); }
+#define PROF_OUT if (lane == 0 && p.pm_out) { for (int i_ = 0; i_ < 16; ++i_) atomicAdd((u64 *)p.pm_out + i_, prof_acc[i_]); }
+#define PROF_CNT(i, v) { prof_acc[i] += (u64)(v); }
 #else
 #define PROF_DECL
 #define PROF(i)
+#define PROF_CNT(i, v)
 #define PROF_OUT
 #endif
 
@@ -608,7 +610,9 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 const double gmax = group_reduce<GS, true>(gm, lane);
                 const double bmin = group_reduce<GS, false>(bl, lane);
                 const bool fastok = (nact == 0) || (nact == L && gmax < bmin);
+                PROF_CNT(8, 1)
                 if (__all(fastok)) {
+                    PROF_CNT(9, 1)
                     if (active) {
                         ubit = (leaf < 0) ? 1u : 0u;
                         pm = gm;
@@ -662,6 +666,17 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     u64 any_i = 0;                                       // bit i: some group has a competitive bad fork i
 #pragma unroll
                     for (int g = 0; g < 64 / GS; ++g) any_i |= (cbm >> (g * GS)) & gmask;
+                    PROF_CNT(10, 1)
+                    PROF_CNT(11, __popcll(any_i))
+#ifdef POLAR_PROFILE
+                    {   // statistics only: good forks that some bad fork of their group could displace
+                        const double bmin_true = group_reduce<GS, false>(active ? mb : __builtin_inf(), lane);
+                        const u64 cgm = __ballot(active && !(mg < bmin_true));
+                        u64 any_g = 0;
+                        for (int g = 0; g < 64 / GS; ++g) any_g |= (cgm >> (g * GS)) & gmask;
+                        PROF_CNT(12, __popcll(any_g))
+                    }
+#endif
                     for (u64 mi = any_i; mi; mi &= mi - 1) {
                         const int i = __builtin_ctzll(mi);
                         const double v = sbb[i];

@@ -35,5 +35,10 @@ dt = time.perf_counter() - t
 a = prof[:16].cpu().numpy().astype(float)
 names = ["loop ovh", "layer S>SL g (HBM)", "layer S>SL f (HBM)", "layer 4<=S<=SL (LDS)", "layer S<4", "leaf frozen / rate-0 block", "leaf unfrozen (rest: flush etc.)", "partial sums", "unf: DPP reductions+decision", "unf: competitive-bad loop", "unf: stack/srcof", "unf: clone shuffles+update", "-", "unf: setup+goods rank loop", "unf: wait for leaf (ballot)", "unf: softplus+bounds"]
 print(f"L={L} B={B} time {dt*1e3:.2f} ms -> {B/dt:.0f} cw/s")
-for nm, v in zip(names, a):
-    print(f"  {nm:24s} {100*v/a.sum():5.1f}%")
+cyc = a[:8].sum()
+for nm, v in zip(names[:8], a[:8]):
+    print(f"  {nm:34s} {100*v/cyc:5.1f}%")
+if a[8] > 0:
+    print(f"  unfrozen steps (per wave) {a[8]:.0f}: fast path {100*a[9]/a[8]:.1f}%, full-list ranking {100*a[10]/a[8]:.1f}%")
+    if a[10] > 0:
+        print(f"  per ranking step: competitive bad forks (union over groups) {a[11]/a[10]:.2f}, contested good forks {a[12]/a[10]:.2f}")
