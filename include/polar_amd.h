@@ -141,6 +141,19 @@ int polar_mc_batch_bicm(polar_code_t *h, int constellation, uint64_t seed, uint6
                         const double *snr_db, int n_s, const uint8_t *L, int n_L,
                         const uint8_t *enabled, uint64_t *err, uint64_t *run);
 
+/* ---- Monte-Carlo code construction (PolarM/PolarCode.m:143-196 `monte_carlo`, receiver 'bicm',
+ * with the genie-aided SC decoder `polar_decode_monte` :897-914). No handle: the result is what a
+ * code is built FROM. For runs trial0 .. trial0+num_runs-1 (counter-based inputs, polar_synth.h):
+ * N random message bits, polar transform, `constellation` (POLAR_CONST_BPSK or _ASK{4,8,16}_GRAY)
+ * at the design SNR (sigma = sqrt(1/2) * 10^(-snr/20), n0 = sigma^2, :170), BICM p1, genie SC;
+ * num_err[i] (host uint64 [2^n]) is INCREMENTED by the number of runs whose position i decided
+ * wrongly — the table the reference writes to CodeConstructionData/MC_block_length_*.txt (:120-124)
+ * and turns into a frozen set by a stable ascending sort (:126-135; polar_create_explicit /
+ * PolarCode.from_counts). `batch` = runs per launch (0 = default). Disjoint trial ranges may be
+ * summed across GPUs. */
+int polar_mc_construction(int n, int constellation, double design_snr_db, uint64_t seed, uint64_t trial0,
+                          long num_runs, long batch, uint64_t *num_err);
+
 /* tuning knobs (0 = default): waves resident per CU and LDS-resident layer exponent */
 int polar_set_tuning(polar_code_t *h, int waves_per_cu, int lds_log);
 

@@ -175,13 +175,19 @@ POLAR_SYNTH_FN double polar_synth_llr(double s, int coded_bit, double z) {
 #define POLAR_CONST_ASK4_GRAY 1
 #define POLAR_CONST_ASK8_GRAY 2
 #define POLAR_CONST_ASK16_GRAY 3
+#define POLAR_CONST_BPSK 4          /* Constellation.m:19 bpsk = [1 -1] (the default of the MC code construction) */
+#define POLAR_SYNTH_STREAM_MCINFO 3u
 
-POLAR_SYNTH_FN int polar_const_nbits(int id) { return id == POLAR_CONST_ASK4_GRAY ? 2 : (id == POLAR_CONST_ASK8_GRAY ? 3 : 4); }
+POLAR_SYNTH_FN int polar_const_nbits(int id) {
+    return id == POLAR_CONST_BPSK ? 1 : (id == POLAR_CONST_ASK4_GRAY ? 2 : (id == POLAR_CONST_ASK8_GRAY ? 3 : 4));
+}
 
 /* un-normalised integer levels (Constellation.m:21,25,29-30) and the sqrt() divisor */
 POLAR_SYNTH_FN double polar_const_point(int id, int sym) {
     double lvl, div;
-    if (id == POLAR_CONST_ASK4_GRAY) {
+    if (id == POLAR_CONST_BPSK) {
+        lvl = (sym & 1) ? -1.0 : 1.0; div = 1.0;
+    } else if (id == POLAR_CONST_ASK4_GRAY) {
         const int t[4] = {-3, -1, 3, 1};
         lvl = (double)t[sym & 3]; div = 5.0;
     } else if (id == POLAR_CONST_ASK8_GRAY) {
@@ -227,9 +233,10 @@ POLAR_SYNTH_FN double polar_synth_exp_neg(double x) {
     return p * v.d;
 }
 
-/* one received symbol -> n_bits LLRs, Constellation.m:123-144: p_sym = exp(-|y-x|^2/2/n0),
- * llr = log(p0/p1) */
-POLAR_SYNTH_FN void polar_synth_bicm_demap(int id, double norm, double y, double n0, double *llr_out) {
+/* one received symbol -> n_bits LLRs and/or bit probabilities, Constellation.m:123-144:
+ * p_sym = exp(-|y-x|^2/2/n0), llr = log(p0/p1) (:142), p1 = p1/(p0+p1) (:143). Either output
+ * pointer may be NULL. */
+POLAR_SYNTH_FN void polar_synth_bicm_demap2(int id, double norm, double y, double n0, double *llr_out, double *p1_out) {
     const int nb = polar_const_nbits(id), ns = 1 << nb;
     double p0[4] = {0, 0, 0, 0}, p1[4] = {0, 0, 0, 0};
     for (int s = 0; s < ns; ++s) {
@@ -240,7 +247,20 @@ POLAR_SYNTH_FN void polar_synth_bicm_demap(int id, double norm, double y, double
             if (((s >> m) & 1) == 0) p0[m] = p0[m] + ps; else p1[m] = p1[m] + ps;
         }
     }
-    for (int m = 0; m < nb; ++m) llr_out[m] = polar_synth_log(p0[m] / p1[m]);
+    for (int m = 0; m < nb; ++m) {
+        if (llr_out) llr_out[m] = polar_synth_log(p0[m] / p1[m]);
+        if (p1_out) p1_out[m] = p1[m] / (p0[m] + p1[m]);
+    }
+}
+POLAR_SYNTH_FN void polar_synth_bicm_demap(int id, double norm, double y, double n0, double *llr_out) {
+    polar_synth_bicm_demap2(id, norm, y, n0, llr_out, (double *)0);
+}
+
+/* 128 of the N random message bits of Monte-Carlo construction run `trial` (PolarCode.m:153:
+ * dummy_info = rand(1, N) < 0.5, fresh for every run); same bit addressing as polar_synth_info_word */
+POLAR_SYNTH_FN void polar_synth_mc_info_word(uint64_t seed, uint64_t trial, uint32_t w, uint32_t out[4]) {
+    polar_philox4x32(w, (uint32_t)trial, (uint32_t)(trial >> 32), POLAR_SYNTH_STREAM_MCINFO,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), out);
 }
 
 /* N(0,1) variate for symbol `sym` of trial `trial` (one Box-Muller pair per two symbols) */

@@ -781,3 +781,66 @@ void orc_mc_batch_bicm(void *h, int cid, uint64_t seed, uint64_t t0, long T, lon
                        const uint8_t *Ls, int n_L, const uint8_t *enabled, uint64_t *err, uint64_t *run) {
     orc_mc_batch_impl(h, cid, seed, t0, T, stride, snr_db, n_s, Ls, n_L, enabled, err, run);
 }
+
+/* ---------- Monte-Carlo code construction: PolarM PolarCode.m:143-196 `monte_carlo` (receiver
+ * 'bicm') with `polar_encode` (:855-867) and the genie-aided `polar_decode_monte` (:897-914),
+ * restated as the same RECURSIONS the MATLAB text uses (the device kernel is iterative and keeps
+ * layers in bit-reversed order, so this is an independent formulation). MATLAB cannot run in the
+ * build image: "parity unpinned" by the reference for this part; the random inputs come from the
+ * counter-based generator of include/polar_synth.h instead of MATLAB's rand/randn. ---------- */
+static void mc_encode_rec(const uint8_t *u, int N, uint8_t *x) {             /* :855-867 */
+    if (N == 1) { x[0] = u[0]; return; }
+    uint8_t *a = (uint8_t *)malloc((size_t)N);
+    uint8_t *b = a + N / 2;
+    for (int k = 0; k < N / 2; ++k) { a[k] = (uint8_t)((u[2 * k] + u[2 * k + 1]) % 2); b[k] = u[2 * k + 1]; }
+    mc_encode_rec(a, N / 2, x);
+    mc_encode_rec(b, N / 2, x + N / 2);
+    free(a);
+}
+static double mc_cnop(double w1, double w2) { return w1 * (1 - w2) + w2 * (1 - w1); }            /* :889-891 */
+static double mc_vnop(double w1, double w2) { return w1 * w2 / (w1 * w2 + (1 - w1) * (1 - w2)); } /* :893-895 */
+static void mc_decode_monte_rec(const double *y, const uint8_t *info, int N, double *x, uint8_t *ber) {   /* :897-914 */
+    if (N == 1) {
+        if ((y[0] > 0.5 && info[0] == 1) || (y[0] <= 0.5 && info[0] == 0)) ber[0] = 0; else ber[0] = 1;
+        x[0] = (double)info[0];
+        return;
+    }
+    double *est = (double *)malloc(sizeof(double) * (size_t)N * 2);
+    double *x1 = est + N / 2, *x2 = x1 + N / 2;
+    for (int k = 0; k < N / 2; ++k) est[k] = mc_cnop(y[2 * k], y[2 * k + 1]);
+    mc_decode_monte_rec(est, info, N / 2, x1, ber);
+    for (int k = 0; k < N / 2; ++k) est[k] = mc_vnop(mc_cnop(x1[k], y[2 * k]), y[2 * k + 1]);
+    mc_decode_monte_rec(est, info + N / 2, N / 2, x2, ber + N / 2);
+    for (int k = 0; k < N / 2; ++k) { x[2 * k] = mc_cnop(x1[k], x2[k]); x[2 * k + 1] = x2[k]; }
+    free(est);
+}
+/* one run: fills p1[N] (may be NULL) and adds the per-position error flags to num_err[N] */
+void orc_mc_construction_run(int n, int cid, double design_snr_db, uint64_t seed, uint64_t trial, double *p1_out, uint64_t *num_err) {
+    const int N = 1 << n, nb = polar_const_nbits(cid), nsym = N / nb;
+    uint8_t *info = (uint8_t *)malloc((size_t)N * 3), *coded = info + N, *ber = coded + N;
+    double *p1 = (double *)malloc(sizeof(double) * (size_t)N * 2), *x = p1 + N;
+    for (int w = 0; w * 128 < N; ++w) {
+        uint32_t r[4];
+        polar_synth_mc_info_word(seed, trial, (uint32_t)w, r);
+        for (int i = 0; i < 128 && w * 128 + i < N; ++i) info[w * 128 + i] = (uint8_t)((r[(i >> 5) & 3] >> (i & 31)) & 1u);
+    }
+    mc_encode_rec(info, N, coded);
+    const double norm = polar_const_norm(cid);
+    const double sigma = sqrt(1.0 / 2) * pow(10.0, -design_snr_db / 20);      /* :170 */
+    const double n0 = sigma * sigma;
+    for (int i = 0; i < N; ++i) p1[i] = 0.5;                                   /* :176 */
+    for (int i = 0; i < nsym; ++i) {
+        int sym = 0;
+        for (int j = 0; j < nb; ++j) sym += (1 << j) * coded[i * nb + j];
+        double xs = polar_const_point(cid, sym) / norm;
+        double y = xs + sigma * polar_synth_symbol_noise(seed, trial, (uint32_t)i);   /* :171-172 */
+        polar_synth_bicm_demap2(cid, norm, y, n0, NULL, p1 + (size_t)i * nb);         /* :178 */
+    }
+    mc_decode_monte_rec(p1, info, N, x, ber);
+    for (int i = 0; i < N; ++i) num_err[i] += ber[i];
+    if (p1_out) memcpy(p1_out, p1, sizeof(double) * (size_t)N);
+    free(info); free(p1);
+}
+void orc_mc_construction(int n, int cid, double design_snr_db, uint64_t seed, uint64_t trial0, long num_runs, uint64_t *num_err) {
+    for (long t = 0; t < num_runs; ++t) orc_mc_construction_run(n, cid, design_snr_db, seed, trial0 + (uint64_t)t, NULL, num_err);
+}

@@ -25,7 +25,16 @@ _u16p = C.POINTER(C.c_uint16)
 _u64p = C.POINTER(C.c_uint64)
 
 
-ASK4_GRAY, ASK8_GRAY, ASK16_GRAY = 1, 2, 3   # include/polar_synth.h POLAR_CONST_*
+ASK4_GRAY, ASK8_GRAY, ASK16_GRAY, BPSK = 1, 2, 3, 4   # include/polar_synth.h POLAR_CONST_*
+CONSTELLATION_NAMES = {"bpsk": BPSK, "ask4-gray": ASK4_GRAY, "ask8-gray": ASK8_GRAY, "ask16-gray": ASK16_GRAY}   # Constellation.m:41-59
+
+
+def _constellation_id(c):
+    if isinstance(c, str):
+        if c not in CONSTELLATION_NAMES:
+            raise PolarError(f"unsupported constellation {c!r} (supported: {sorted(CONSTELLATION_NAMES)})")
+        return CONSTELLATION_NAMES[c]
+    return int(c)
 
 
 class PolarError(RuntimeError):
@@ -122,15 +131,64 @@ class PolarCode:
         per-channel error count per line, written at PolarCode.m:120-124). As PolarCode.m:126-135:
         stable ascending sort of the counts, the first K+crc positions are the unfrozen set and their
         order is the info-bit order."""
-        counts = np.loadtxt(path).reshape(-1)
+        return cls.from_counts(np.loadtxt(path).reshape(-1), info_length, crc_size, crc_matrix)
+
+    @classmethod
+    def from_counts(cls, counts, info_length, crc_size=0, crc_matrix=None):
+        """Code from a per-channel error-count table (PolarCode.m:126-135): stable ascending sort,
+        the first K+crc positions are the unfrozen set and their order is the info-bit order."""
+        counts = np.asarray(counts).reshape(-1)
         N = counts.size
         n = int(round(np.log2(N)))
         if (1 << n) != N:
-            raise PolarError("construction file must hold a power-of-two number of lines")
+            raise PolarError("the count table must hold a power-of-two number of entries")
         order = np.argsort(counts, kind="stable").astype(np.uint16)
         frozen = np.ones(N, np.uint8)
         frozen[order[: info_length + crc_size]] = 0
         return cls.from_tables(n, info_length, crc_size, frozen, order, crc_matrix)
+
+    @classmethod
+    def from_monte_carlo(cls, block_length, info_length, design_snr_db, crc_size=0, num_runs=100000,
+                         constellation_name="bpsk", receiver_algo="bicm", seed=1, crc_matrix=None, data_dir=None):
+        """Code designed by PolarM's `monte_carlo_code_construction` (PolarCode.m:95-141): same argument
+        meaning and defaults; the genie-aided SC runs on the GPU (mc_construction).
+        With ``data_dir`` the table is read from / written to
+        ``MC_block_length_<unique string>.txt`` exactly as the reference does (:111-124)."""
+        if receiver_algo != "bicm":
+            raise PolarError("only the 'bicm' receiver is built (SURVEY §2: the MLC demapper is out of scope)")
+        path = None
+        if data_dir is not None:
+            path = os.path.join(data_dir, "MC_block_length_" + construction_unique_string(
+                block_length, info_length + crc_size, design_snr_db, constellation_name, receiver_algo, num_runs) + ".txt")
+        if path is not None and os.path.exists(path):
+            counts = np.loadtxt(path).reshape(-1)
+        else:
+            n = int(round(np.log2(block_length)))
+            if (1 << n) != block_length:
+                raise PolarError("block_length must be a power of two")
+            counts = mc_construction(n, design_snr_db, num_runs, constellation_name, seed=seed)
+            if path is not None:
+                write_construction_file(path, counts)
+        if crc_size and crc_matrix is None:      # PolarCode.m:83: crc_matrix = floor(2*rand(crc_size, info_length))
+            crc_matrix = np.random.default_rng(seed).integers(0, 2, (crc_size, info_length)).astype(np.uint8)
+        code = cls.from_counts(counts, info_length, crc_size, crc_matrix)
+        code.construction_counts = np.asarray(counts)
+        # PolarCode.m:136: bler_estimate = sum(channels(info_bits)) / num_runs
+        code.bler_estimate = float(np.sort(np.asarray(counts, np.float64), kind="stable")[: info_length + crc_size].sum() / num_runs)
+        return code
+
+    def monte_carlo_code_construction(self, design_snr_db, num_runs=100000, constellation_name="bpsk",
+                                      receiver_algo="bicm", seed=1, data_dir=None):
+        """In-place redesign of this code, as the reference method of the same name
+        (PolarCode.m:95-141): block length, K, crc size and the crc matrix are kept, the frozen set and
+        info-bit order are replaced."""
+        cm = self.crc_matrix if self.crc_size else None
+        new = PolarCode.from_monte_carlo(self.block_length, self.info_length, design_snr_db, self.crc_size, num_runs,
+                                         constellation_name, receiver_algo, seed, cm, data_dir)
+        self.close()
+        self._h, new._h = new._h, None
+        self.construction_counts, self.bler_estimate = new.construction_counts, new.bler_estimate
+        return self.bler_estimate
 
     def close(self):
         if getattr(self, "_h", None):
@@ -283,3 +341,38 @@ class PolarCode:
                                           C.c_long(max_runs), C.c_long(max_err), C.c_uint64(seed), C.c_long(batch),
                                           _p(out, _dp)))
         return out
+
+
+# ---- Monte-Carlo code construction (PolarM/PolarCode.m:95-196) ---------------------------------
+def _num2str(x):
+    """MATLAB num2str for the values the reference puts in file names (integers and short decimals)."""
+    return str(int(x)) if float(x) == int(x) else ("%.4f" % float(x)).rstrip("0").rstrip(".")
+
+
+def construction_unique_string(block_length, num_info_bits, design_snr_db, constellation_name="bpsk",
+                               receiver_algo="bicm", num_runs=20000):
+    """get_unique_string (PolarCode.m:258-261) for cc_method 'monte-carlo' (:107-109)."""
+    return (f"{_num2str(block_length)}_{_num2str(num_info_bits)}_cc_method_monte-carlo_cc_param_"
+            f"{_num2str(design_snr_db)}_{constellation_name}_{receiver_algo}_{_num2str(num_runs)}")
+
+
+def write_construction_file(path, counts):
+    """One count per line, '%d \n' (PolarCode.m:120-124)."""
+    with open(path, "w") as f:
+        for c in np.asarray(counts).reshape(-1):
+            f.write("%d \n" % int(c))
+
+
+def mc_construction(num_layers, design_snr_db, num_runs, constellation="bpsk", seed=1, trial0=0, batch=0, out=None):
+    """Per-position error counts of the genie-aided SC decoder over ``num_runs`` Monte-Carlo runs
+    (PolarCode.m:143-196 `monte_carlo`, 'bicm' receiver), computed on the GPU. Returns uint64[N];
+    with ``out`` the counts are ADDED to it (shards of one trial range, see montecarlo.py)."""
+    N = 1 << num_layers
+    if out is None:
+        out = np.zeros(N, np.uint64)
+    if out.dtype != np.uint64 or out.shape != (N,) or not out.flags.c_contiguous:
+        raise PolarError("out must be a contiguous uint64[N] array")
+    _check(lib().polar_mc_construction(C.c_int(num_layers), C.c_int(_constellation_id(constellation)),
+                                       C.c_double(design_snr_db), C.c_uint64(seed), C.c_uint64(trial0),
+                                       C.c_long(num_runs), C.c_long(batch), _p(out, _u64p)))
+    return out

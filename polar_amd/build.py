@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(ROOT, "include")
 LIB = os.path.join(HERE, "libpolar_amd.so")
 BUILD = os.path.join(HERE, "_build")
-SOURCES = ["polar_kernels.hip", "polar_kernels_p1.hip", "polar_channel.hip", "polar_host.cpp"]
+SOURCES = ["polar_kernels.hip", "polar_kernels_p1.hip", "polar_channel.hip", "polar_construct.hip", "polar_host.cpp"]
 ARCH = "gfx950"
 
 

@@ -611,6 +611,54 @@ int polar_synth_bicm_llr_dev(polar_code_t *h, int constellation, uint64_t seed, 
     return POLAR_OK;
 }
 
+int polar_mc_construction(int n, int constellation, double design_snr_db, uint64_t seed, uint64_t trial0,
+                          long num_runs, long batch, uint64_t *num_err) {
+    if (!num_err) return fail(POLAR_E_ARG, "NULL argument");
+    if (n < 1 || n > POLAR_MAX_N_LOG2) return fail(POLAR_E_ARG, "n = %d out of range [1, %d]", n, POLAR_MAX_N_LOG2);
+    if (constellation < POLAR_CONST_ASK4_GRAY || constellation > POLAR_CONST_BPSK)
+        return fail(POLAR_E_ARG, "unknown constellation %d", constellation);
+    if (num_runs < 0 || batch < 0) return fail(POLAR_E_ARG, "negative run count");
+    if (num_runs == 0) return POLAR_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(POLAR_E_DEVICE, "no HIP device: the Monte-Carlo construction has no CPU path");
+    const int N = 1 << n, words = (N + 31) / 32;
+    if (batch == 0) batch = std::max<long>(64, std::min<long>(32768, (256L << 20) / ((long)N * 8)));   // <= 256 MiB of p1
+    batch = std::min(batch, num_runs);
+    const int grid = (int)std::min<long>((batch + 63) / 64, 8192);
+    DevBuf<double> d_p1, d_y;
+    DevBuf<uint32_t> d_info;
+    DevBuf<uint8_t> d_x;
+    DevBuf<unsigned long long> d_cnt;
+    int rc;
+    struct Guard {
+        DevBuf<double> &a, &b; DevBuf<uint32_t> &c; DevBuf<uint8_t> &d; DevBuf<unsigned long long> &e;
+        ~Guard() { a.release(); b.release(); c.release(); d.release(); e.release(); }
+    } guard{d_p1, d_y, d_info, d_x, d_cnt};
+    if ((rc = d_p1.ensure((size_t)batch * N))) return rc;
+    if ((rc = d_info.ensure((size_t)batch * words))) return rc;
+    if ((rc = d_y.ensure((size_t)grid * N * 64))) return rc;
+    if ((rc = d_x.ensure((size_t)grid * 2 * N * 64))) return rc;
+    if ((rc = d_cnt.ensure((size_t)N))) return rc;
+    HIP_TRY(hipMemset(d_cnt.p, 0, (size_t)N * sizeof(unsigned long long)));
+    PolarConstructParams p;
+    p.n = n; p.N = N; p.seed = seed; p.constellation = constellation;
+    p.sigma = std::sqrt(1.0 / 2) * std::pow(10.0, -design_snr_db / 20);          // PolarCode.m:170
+    p.n0 = p.sigma * p.sigma;
+    p.cnorm = polar_const_norm(constellation);
+    p.p1 = d_p1.p; p.info = d_info.p; p.y_scr = d_y.p; p.x_scr = d_x.p; p.num_err = d_cnt.p;
+    for (long t = 0; t < num_runs; t += batch) {
+        p.B = std::min(batch, num_runs - t);
+        p.trial0 = trial0 + (uint64_t)t;
+        HIP_TRY(polar_launch_mc_front(p, (int)std::min<long>(p.B, 8192), nullptr));
+        HIP_TRY(polar_launch_mc_genie(p, (int)std::min<long>((p.B + 63) / 64, grid), nullptr));
+    }
+    std::vector<unsigned long long> cnt(N);
+    HIP_TRY(hipMemcpy(cnt.data(), d_cnt.p, (size_t)N * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int i = 0; i < N; ++i) num_err[i] += (uint64_t)cnt[i];
+    return POLAR_OK;
+}
+
 int polar_get_bler_quick(polar_code_t *h, const double *ebno, int n_e, const uint8_t *Ls, int n_L,
                          long max_runs, long max_err, uint64_t seed, long batch, double *bler_out) {
     if (!h || !ebno || !Ls || !bler_out) return fail(POLAR_E_ARG, "NULL argument");

@@ -42,6 +42,22 @@ struct PolarScP1Params {
 };
 hipError_t polar_launch_sc_p1(const PolarScP1Params &p, int grid, hipStream_t st);
 
+// Monte-Carlo code construction (polar_construct.hip)
+struct PolarConstructParams {
+    int n, N;
+    long B;                      // runs in this batch
+    uint64_t seed, trial0;       // run b uses trial index trial0 + b
+    int constellation;           // POLAR_CONST_*
+    double sigma, n0, cnorm;
+    double *p1;                  // [B][N] device: P(bit = 1) per position
+    uint32_t *info;              // [B][ceil(N/32)] device: packed message bits
+    double *y_scr;               // per-wave scratch [grid][N][64]
+    uint8_t *x_scr;              // per-wave scratch [grid][2*N][64]
+    unsigned long long *num_err; // [N] device accumulators
+};
+hipError_t polar_launch_mc_front(const PolarConstructParams &p, int grid, hipStream_t st);
+hipError_t polar_launch_mc_genie(const PolarConstructParams &p, int grid, hipStream_t st);
+
 struct PolarEncodeParams {
     int n, N, K, crc;
     long B;

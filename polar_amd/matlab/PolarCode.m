@@ -15,6 +15,9 @@ classdef PolarCode < handle
         frozen_bits      % 1 x N, in decoding order (as PolarM)
         info_bits        % 1-based positions of the K+crc unfrozen bits, most reliable first
         crc_matrix
+        cc_method        % 'bhattacharya' | 'monte-carlo' (as PolarM :89, :107)
+        cc_parameter
+        cc_misc
     end
     properties (Access = private)
         h                % uint64 handle owned by the MEX gateway
@@ -34,6 +37,48 @@ classdef PolarCode < handle
             obj.frozen_bits = double(fz(:)');
             obj.info_bits = double(order(1:info_length + crc_size)) + 1;
             obj.crc_matrix = double(crcm);
+            obj.cc_method = 'bhattacharya';
+            obj.cc_parameter = design_epsilon;
+            obj.cc_misc = '';
+        end
+        function monte_carlo_code_construction(obj, design_snr_db, num_runs, constellation_name, receiver_algo, seed)
+            % Same name, arguments and defaults as PolarM/PolarCode.m:95-141; the genie-aided SC runs
+            % on the GPU (polar_mc_construction), the table is cached in CodeConstructionData/ under the
+            % reference's file name and format.
+            if (nargin < 3) || isempty(num_runs), num_runs = 100e3; end
+            if (nargin < 4) || isempty(constellation_name), constellation_name = 'bpsk'; end
+            if (nargin < 5) || isempty(receiver_algo), receiver_algo = 'bicm'; end
+            if nargin < 6, seed = 1; end
+            if ~strcmp(receiver_algo, 'bicm'), error('only the bicm receiver is built'); end
+            ids = struct('bpsk', 4, 'ask4_gray', 1, 'ask8_gray', 2, 'ask16_gray', 3);
+            cid = ids.(strrep(constellation_name, '-', '_'));
+            obj.cc_method = 'monte-carlo';
+            obj.cc_parameter = design_snr_db;
+            obj.cc_misc = [constellation_name, '_', receiver_algo, '_', num2str(num_runs)];
+            txt_file_name = ['CodeConstructionData/MC_block_length_', obj.get_unique_string(), '.txt'];
+            if exist(txt_file_name, 'file')
+                channels = load(txt_file_name);
+            else
+                channels = polar_mex('mc_construction', obj.n, cid, design_snr_db, seed, num_runs);
+                fileID = fopen(txt_file_name, 'w');
+                if fileID > 0
+                    fprintf(fileID, '%d \n', channels);
+                    fclose(fileID);
+                end
+            end
+            [~, channel_order] = sort(channels(:)', 'ascend');          % MATLAB's sort is stable
+            n_info = obj.info_length + obj.crc_size;
+            obj.info_bits = channel_order(1:n_info);
+            obj.frozen_bits = ones(1, obj.block_length);
+            obj.frozen_bits(obj.info_bits) = 0;
+            polar_mex('destroy', obj.h);
+            obj.h = polar_mex('create_explicit', obj.n, obj.info_length, obj.crc_size, uint8(obj.frozen_bits), ...
+                              uint16(channel_order - 1), uint8(obj.crc_matrix));
+            disp(['Monte carlo code construction done. Bler estimate = ', num2str(sum(channels(obj.info_bits)) / num_runs)]);
+        end
+        function unique_string = get_unique_string(obj)                % PolarM :258-261
+            unique_string = [num2str(obj.block_length), '_', num2str(length(obj.info_bits)), ...
+                '_cc_method_', obj.cc_method, '_cc_param_', num2str(obj.cc_parameter), '_', obj.cc_misc];
         end
         function delete(obj)
             if ~isempty(obj.h)

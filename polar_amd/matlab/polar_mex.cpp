@@ -27,6 +27,33 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         *(uint64_t *)mxGetData(plhs[0]) = (uint64_t)(uintptr_t)h;
         return;
     }
+    if (c == "create_explicit") {
+        // polar_mex('create_explicit', n, K, crc, frozen(uint8 1xN), order(uint16 1xN, 0-based), crc_matrix(uint8 crc x K))
+        const int n_ = (int)mxGetScalar(prhs[1]), K_ = (int)mxGetScalar(prhs[2]), crc_ = (int)mxGetScalar(prhs[3]);
+        std::vector<uint8_t> m((size_t)crc_ * K_);
+        if (crc_ > 0) {
+            const uint8_t *d = (const uint8_t *)mxGetData(prhs[6]);           // column-major crc x K
+            for (int i = 0; i < crc_; ++i)
+                for (int j = 0; j < K_; ++j) m[(size_t)i * K_ + j] = d[(size_t)j * crc_ + i];
+        }
+        polar_code_t *h = nullptr;
+        check(polar_create_explicit(n_, K_, crc_, (const uint8_t *)mxGetData(prhs[4]), (const uint16_t *)mxGetData(prhs[5]),
+                                    crc_ > 0 ? m.data() : nullptr, &h));
+        mexLock();
+        plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
+        *(uint64_t *)mxGetData(plhs[0]) = (uint64_t)(uintptr_t)h;
+        return;
+    }
+    if (c == "mc_construction") {
+        // counts = polar_mex('mc_construction', n, constellation_id, design_snr_db, seed, num_runs)  (PolarCode.m:143-196)
+        const int n_ = (int)mxGetScalar(prhs[1]);
+        std::vector<uint64_t> cnt((size_t)1 << n_, 0);
+        check(polar_mc_construction(n_, (int)mxGetScalar(prhs[2]), mxGetScalar(prhs[3]), (uint64_t)mxGetScalar(prhs[4]), 0,
+                                    (long)mxGetScalar(prhs[5]), 0, cnt.data()));
+        plhs[0] = mxCreateDoubleMatrix((mwSize)cnt.size(), 1, mxREAL);
+        for (size_t i = 0; i < cnt.size(); ++i) mxGetPr(plhs[0])[i] = (double)cnt[i];
+        return;
+    }
     polar_code_t *h = H(prhs[1]);
     int n, N, K, crc;
     check(polar_get_params(h, &n, &N, &K, &crc));

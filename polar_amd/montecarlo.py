@@ -61,3 +61,25 @@ def get_bler_quick_sharded(engine, ebno_vec, list_size_vec, max_runs=1000, max_e
         base += gb
     bler = np.where(run > 0, err.astype(np.float64) / np.maximum(run, 1).astype(np.float64), 0.0)
     return bler, err, run
+
+
+def mc_construction_sharded(counter, num_layers, design_snr_db, num_runs, constellation, seed=1, device=None):
+    """Monte-Carlo code construction (PolarCode.m:143-196) sharded over GPUs: runs 0..num_runs-1 are
+    split into `world` contiguous ranges, rank r counts its range with
+    counter(num_layers, design_snr_db, runs, constellation, seed=, trial0=) -> uint64[N]
+    (polar_amd.mc_construction on a GPU) and ONE all-reduce (sum, int64[N]) merges the tables.
+    The runs are counter-based, so the table does not depend on the world size."""
+    rank, world = _world()
+    lo = (num_runs * rank) // world
+    hi = (num_runs * (rank + 1)) // world
+    N = 1 << num_layers
+    cnt = np.zeros(N, np.uint64)
+    if hi > lo:
+        cnt = np.asarray(counter(num_layers, design_snr_db, hi - lo, constellation, seed=seed, trial0=lo), np.uint64)
+    if world > 1:
+        t = torch.from_numpy(cnt.astype(np.int64))
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t)
+        cnt = t.cpu().numpy().astype(np.uint64)
+    return cnt

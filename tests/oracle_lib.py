@@ -205,3 +205,27 @@ class Oracle(_Base):
         self._call("mc_batch_bicm", C.c_int(cid), C.c_uint64(seed), C.c_uint64(t0), C.c_long(T), C.c_long(stride),
                    _p(snr, _dp), C.c_int(len(snr)), _p(Ls, _u8p), C.c_int(len(Ls)), _p(enabled, _u8p),
                    _p(err, _u64p), _p(run, _u64p))
+
+
+def mc_construction(n, cid, design_snr_db, seed, trial0, num_runs):
+    """oracle/polar_oracle.c orc_mc_construction: per-position genie-SC error counts."""
+    if not os.path.exists(ORACLE_SO):
+        build_oracle()
+    lib = C.CDLL(ORACLE_SO)
+    cnt = np.zeros(1 << n, np.uint64)
+    lib.orc_mc_construction(C.c_int(n), C.c_int(cid), C.c_double(design_snr_db), C.c_uint64(seed), C.c_uint64(trial0),
+                            C.c_long(num_runs), _p(cnt, _u64p))
+    return cnt
+
+
+def mc_construction_run(n, cid, design_snr_db, seed, trial):
+    """One run: (p1[N], error flags[N])."""
+    if not os.path.exists(ORACLE_SO):
+        build_oracle()
+    lib = C.CDLL(ORACLE_SO)
+    N = 1 << n
+    p1 = np.zeros(N, np.float64)
+    cnt = np.zeros(N, np.uint64)
+    lib.orc_mc_construction_run(C.c_int(n), C.c_int(cid), C.c_double(design_snr_db), C.c_uint64(seed), C.c_uint64(trial),
+                                _p(p1, _dp), _p(cnt, _u64p))
+    return p1, cnt.astype(np.uint8)

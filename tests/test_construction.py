@@ -1,0 +1,204 @@
+"""Monte-Carlo code construction: PolarM `monte_carlo` ('bicm' receiver,
+PolarCode.m:143-196) with the genie-aided SC decoder `polar_decode_monte` (:897-914).
+
+MATLAB cannot run in the build image and the reference seeds nothing, so this row is 'parity
+unpinned' by the reference. What is checked instead:
+  * CPU: the C restatement (oracle/polar_oracle.c) against an independent numpy/Python evaluation
+    of the same MATLAB formulas (message bits, polar transform by Kronecker power, modulation,
+    demapper, recursive genie decoder);
+  * GPU: the device kernels against the restatement, count for count (bit-exact bar);
+  * GPU: 250 000 runs at the reference's design point (N=1024, 16-ASK Gray, 13 dB) against the
+    table the reference ships in CodeConstructionData (a data fixture in tests/golden), position
+    by position within Poisson noise, and the resulting frozen set against the reference's."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from test_bicm import LEVELS, _oracle_symbol_noise, _philox
+
+POINTS = dict(LEVELS)
+POINTS[4] = ([1, -1], 1.0)      # Constellation.m:19 bpsk
+
+
+def _mc_info_bits(seed, trial, N):
+    bits = np.zeros(N, np.uint8)
+    for w in range((N + 127) // 128):
+        r = _philox([w, trial & 0xFFFFFFFF, trial >> 32, 3], [seed & 0xFFFFFFFF, seed >> 32])
+        for i in range(min(128, N - 128 * w)):
+            bits[128 * w + i] = (r[(i >> 5) & 3] >> (i & 31)) & 1
+    return bits
+
+
+def _kron_encode(u):
+    """x = u * F^{(x)n} over GF(2), then the bit-reversal readout that the natural recursion of
+    PolarCode.m:855-867 produces."""
+    N = len(u)
+    n = int(np.log2(N))
+    G = np.array([[1]], np.uint8)
+    F = np.array([[1, 0], [1, 1]], np.uint8)
+    for _ in range(n):
+        G = np.kron(G, F)
+    t = (u.astype(np.int64) @ G.astype(np.int64)) % 2
+    rev = [int(format(i, f"0{n}b")[::-1], 2) if n else 0 for i in range(N)]
+    return t[rev].astype(np.uint8)
+
+
+def _cnop(a, b):
+    return a * (1 - b) + b * (1 - a)
+
+
+def _vnop(a, b):
+    return a * b / (a * b + (1 - a) * (1 - b))
+
+
+def _decode_monte(y, info):
+    """PolarCode.m:897-914, vectorised exactly as the MATLAB text."""
+    N = len(y)
+    if N == 1:
+        ok = (y[0] > 0.5 and info[0] == 1) or (y[0] <= 0.5 and info[0] == 0)
+        return np.array([float(info[0])]), np.array([0 if ok else 1], np.uint8)
+    u1est = _cnop(y[0::2], y[1::2])
+    x1, b1 = _decode_monte(u1est, info[: N // 2])
+    u2est = _vnop(_cnop(x1, y[0::2]), y[1::2])
+    x2, b2 = _decode_monte(u2est, info[N // 2:])
+    x = np.empty(N)
+    x[0::2] = _cnop(x1, x2)
+    x[1::2] = x2
+    return x, np.concatenate([b1, b2])
+
+
+def _numpy_p1(coded, cid, noise, snr_db):
+    lv, div = POINTS[cid]
+    pts = np.array(lv, float) / np.sqrt(div)
+    pts = pts / np.sqrt(np.mean(pts ** 2))
+    nb = int(np.log2(len(lv)))
+    N = len(coded)
+    nsym = N // nb
+    bits = coded[: nsym * nb].reshape(-1, nb)
+    sym = (bits * (1 << np.arange(nb))).sum(1)
+    sigma = np.sqrt(0.5) * 10 ** (-snr_db / 20)
+    y = pts[sym] + sigma * noise
+    ps = np.exp(-np.abs(y[:, None] - pts[None, :]) ** 2 / 2 / sigma ** 2)
+    p1 = np.full(N, 0.5)
+    for m in range(nb):
+        b = (np.arange(len(lv)) >> m) & 1
+        s0, s1 = ps[:, b == 0].sum(1), ps[:, b == 1].sum(1)
+        p1[m: nsym * nb: nb] = s1 / (s0 + s1)
+    return p1
+
+
+@pytest.mark.parametrize("n,cid,snr", [(3, 4, 0.0), (6, 4, 1.0), (7, 1, 5.0), (8, 2, 9.0), (8, 3, 12.0), (5, 3, 6.0)])
+def test_oracle_run_matches_independent_numpy(oracle_built, n, cid, snr):
+    N = 1 << n
+    nb = int(np.log2(len(POINTS[cid][0])))
+    for trial in (0, 5, (1 << 33) + 7):
+        p1, flags = oracle_lib.mc_construction_run(n, cid, snr, 42, trial)
+        info = _mc_info_bits(42, trial, N)
+        coded = _kron_encode(info)
+        want_p1 = _numpy_p1(coded, cid, _oracle_symbol_noise(42, trial, N // nb), snr)
+        assert np.allclose(p1, want_p1, rtol=1e-9, atol=1e-12)
+        _, want_flags = _decode_monte(p1, info)          # decoder formulas on the SAME p1: exact
+        assert (flags == want_flags).all()
+    assert (oracle_lib.mc_construction(n, cid, snr, 42, 3, 4)
+            == sum(oracle_lib.mc_construction_run(n, cid, snr, 42, 3 + t)[1].astype(np.uint64) for t in range(4))).all()
+
+
+def test_oracle_counts_polarise(oracle_built):
+    """BPSK at 1 dB, N=256: the error counts follow the polarisation pattern (first position worst,
+    last position best, reliability ordering correlates with the Bhattacharyya construction)."""
+    runs = 300
+    c = oracle_lib.mc_construction(8, 4, 1.0, 7, 0, runs).astype(float)
+    assert c[0] > 0.35 * runs and c[-1] == 0
+    from oracle_lib import Oracle
+    o = Oracle(8, 128, 0.32, 0, srand=1)
+    good = np.zeros(256, bool)
+    good[o.order()[:128]] = True
+    assert c[good].mean() < 0.25 * c[~good].mean()
+
+
+def test_file_name_and_format(tmp_path):
+    import polar_amd
+    s = polar_amd.construction_unique_string(1024, 512, 13, "ask16-gray", "bicm", 250000)
+    # the name of the file the reference ships (PolarM/CodeConstructionData)
+    assert "MC_block_length_" + s + ".txt" == \
+        "MC_block_length_1024_512_cc_method_monte-carlo_cc_param_13_ask16-gray_bicm_250000.txt"
+    assert polar_amd.construction_unique_string(2048, 1040, 2.5, "bpsk", "bicm", 20000).startswith("2048_1040_cc_method_monte-carlo_cc_param_2.5_bpsk")
+    p = tmp_path / "t.txt"
+    polar_amd.write_construction_file(str(p), [3, 0, 12])
+    assert p.read_text() == "3 \n0 \n12 \n"
+    assert (np.loadtxt(str(p)) == [3, 0, 12]).all()
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,cid,snr,runs", [(1, 4, 0.0, 100), (2, 1, 3.0, 130), (5, 4, 1.0, 700), (6, 3, 8.0, 300), (8, 2, 9.0, 200),
+                                            (10, 3, 13.0, 150), (10, 4, 2.0, 100), (11, 4, 2.0, 70)])
+def test_device_counts_match_oracle(built_lib, oracle_built, n, cid, snr, runs):
+    import polar_amd
+    want = oracle_lib.mc_construction(n, cid, snr, 99, 1000, runs)
+    got = polar_amd.mc_construction(n, snr, runs, cid, seed=99, trial0=1000)
+    assert (got == want).all(), np.nonzero(got != want)[0][:10]
+    # batching / accumulation do not change the result
+    acc = np.zeros(1 << n, np.uint64)
+    polar_amd.mc_construction(n, snr, runs // 2, cid, seed=99, trial0=1000, batch=37, out=acc)
+    polar_amd.mc_construction(n, snr, runs - runs // 2, cid, seed=99, trial0=1000 + runs // 2, batch=64, out=acc)
+    assert (acc == want).all()
+
+
+@pytest.mark.gpu
+def test_reference_design_point_statistics(built_lib):
+    """N=1024, 16-ASK Gray, 13 dB, 250 000 runs — the construction the reference ships."""
+    import golden_util as G
+    import polar_amd
+    ref = G.load()[0]["cfg5_n10_k512_ask16/counts"].astype(np.float64)
+    runs = 250000
+    got = polar_amd.mc_construction(10, 13.0, runs, "ask16-gray", seed=2024).astype(np.float64)
+    # two independent binomial samples of the same probability: |a-b| <= 6 sigma (+ small-count slack)
+    tol = 6.0 * np.sqrt(ref + got + 1.0) + 3.0
+    bad = np.nonzero(np.abs(got - ref) > tol)[0]
+    assert bad.size == 0, (bad[:10], got[bad[:10]], ref[bad[:10]])
+    assert abs(got.sum() - ref.sum()) < 1e-3 * ref.sum()
+    # frozen set from our counts vs the reference's: only positions near the K-th boundary may differ
+    code = polar_amd.PolarCode.from_counts(got, 512)
+    fr_ref = np.ones(1024, np.uint8)
+    fr_ref[np.argsort(ref, kind="stable")[:512]] = 0
+    diff = np.nonzero(code.frozen_bits != fr_ref)[0]
+    assert diff.size <= 16, diff
+    thr = np.sort(ref)[511]
+    assert (np.abs(ref[diff] - thr) < 6 * np.sqrt(thr) + 10).all()
+
+
+@pytest.mark.gpu
+def test_from_monte_carlo_builds_a_working_code(built_lib, tmp_path):
+    """PolarCode.m:59-141 flow: construct, write the table in the reference's file format, reload it,
+    decode with it: SC BLER of the MC-designed code is no worse than ~the Bhattacharyya design.
+    (The design SNR must be low enough for the information positions to SHOW errors, otherwise the
+    stable sort picks zero-count positions in index order — the reference's own warning, :128-131.)"""
+    import polar_amd
+    code = polar_amd.PolarCode.from_monte_carlo(512, 256, -1.0, crc_size=0, num_runs=20000, data_dir=str(tmp_path))
+    files = os.listdir(tmp_path)
+    assert files == ["MC_block_length_512_256_cc_method_monte-carlo_cc_param_-1_bpsk_bicm_20000.txt"]
+    again = polar_amd.PolarCode.from_monte_carlo(512, 256, -1.0, crc_size=0, num_runs=20000, data_dir=str(tmp_path))
+    assert (again.frozen_bits == code.frozen_bits).all() and (again.channel_order_descending == code.channel_order_descending).all()
+    same = polar_amd.PolarCode.from_construction_file(os.path.join(tmp_path, files[0]), 256)
+    assert (same.frozen_bits == code.frozen_bits).all()
+    assert 0.01 < code.bler_estimate < 1.0      # design point: Es/N0 = -1 dB <=> Eb/N0 = 2 dB at rate 1/2
+    bha = polar_amd.PolarCode(9, 256, 0.32, 0)
+    en = np.ones((1, 1), np.uint8)
+    e1, r1 = np.zeros((1, 1), np.uint64), np.zeros((1, 1), np.uint64)
+    e2, r2 = np.zeros((1, 1), np.uint64), np.zeros((1, 1), np.uint64)
+    code.mc_batch(3, 0, 4000, 1, [2.5], [1], en, e1, r1)
+    bha.mc_batch(3, 0, 4000, 1, [2.5], [1], en, e2, r2)
+    assert e1[0, 0] > 0 and e1[0, 0] < 1.5 * e2[0, 0] + 20, (e1, e2)
+    # the reference's in-place method: same result as the constructor form, crc matrix kept
+    C = __import__("ctypes")
+    C.CDLL(None).srand(1)
+    obj = polar_amd.PolarCode(9, 248, 0.32, 8)
+    cm = obj.crc_matrix.copy()
+    obj.monte_carlo_code_construction(-1.0, 20000, data_dir=str(tmp_path))
+    assert (obj.frozen_bits == code.frozen_bits).all() and (obj.crc_matrix == cm).all()
+    info = np.random.default_rng(1).integers(0, 2, (5, 248)).astype(np.uint8)
+    llr = (1.0 - 2.0 * obj.encode(info).astype(np.float64)) * 8.0         # noiseless: llr > 0 <=> bit 0
+    assert (obj.decode_scl_llr(llr, 4) == info).all()

@@ -17,15 +17,18 @@ import ctypes as C
 import numpy as np
 import torch, torch.distributed as dist
 from oracle_lib import Oracle
-from polar_amd.montecarlo import get_bler_quick_sharded
+from polar_amd.montecarlo import get_bler_quick_sharded, mc_construction_sharded
+import oracle_lib
 world = int(os.environ.get("WORLD_SIZE", "1"))
 if world > 1:
     dist.init_process_group(backend="gloo")
 C.CDLL(None).srand(1)
 o = Oracle(7, 64, 0.32, 4)
 bler, err, run = get_bler_quick_sharded(o.mc_batch, [1.0, 2.5, 4.0], [1, 4], max_runs=96, max_err=10, seed=11, global_batch=24)
+cnt = mc_construction_sharded(lambda n, snr, runs, cid, seed, trial0: oracle_lib.mc_construction(n, cid, snr, seed, trial0, runs),
+                              6, 1.0, 75, 4, seed=5)
 if (not dist.is_initialized()) or dist.get_rank() == 0:
-    print("RESULT " + json.dumps({"err": err.tolist(), "run": run.tolist(), "bler": bler.tolist()}))
+    print("RESULT " + json.dumps({"err": err.tolist(), "run": run.tolist(), "bler": bler.tolist(), "cnt": cnt.tolist()}))
 if dist.is_initialized():
     dist.destroy_process_group()
 """
@@ -56,3 +59,6 @@ def test_sharded_counters_equal_unsharded(oracle_built, tmp_path):
     assert run.max() <= 96 and (err <= run).all() and run.min() >= 24
     # early stop happened somewhere (low Eb/N0, max_err = 10) and not everywhere
     assert (run < 96).any() and (run == 96).any()
+    # Monte-Carlo construction table: identical for 1 and 2 ranks (checked by a == b), and non-trivial
+    cnt = np.array(a["cnt"])
+    assert cnt.shape == (64,) and cnt[0] > 20 and cnt[-1] == 0
