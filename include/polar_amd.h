@@ -84,6 +84,12 @@ int polar_decode_scl_llr_batch(polar_code_t *h, const double *llr, long B, int L
  * d_pm (optional, may be NULL) receives the winning path metric per codeword. */
 int polar_decode_scl_llr_batch_dev(polar_code_t *h, const double *d_llr, long B, int L, uint8_t *d_out,
                                    double *d_pm, void *stream);
+/* single-precision LLRs at the boundary (half the PCIe / HBM input bytes): every float is widened
+ * exactly to the reference's double on the device, so the result equals decode_scl_llr on
+ * (double)llr[i]. Host-pointer and device-resident forms. */
+int polar_decode_scl_llr_batch_f32(polar_code_t *h, const float *llr, long B, int L, uint8_t *out);
+int polar_decode_scl_llr_batch_dev_f32(polar_code_t *h, const float *d_llr, long B, int L, uint8_t *d_out,
+                                       double *d_pm, void *stream);
 /* same, recording two hipEvent_t (may be NULL) on `stream` immediately around the launch of the
  * dominant kernel (scl_decode_llr_kernel), i.e. after the small all-frozen-prefix kernel — for
  * bench.py's roofline line */

@@ -252,7 +252,16 @@ class PolarCode:
 
     # ---- decoders -----------------------------------------------------------------------
     def decode_scl_llr(self, llr, list_size):
-        """PolarCode::decode_scl_llr (PolarCode.cpp:130-148). `llr` is [N] or [B, N] float64."""
+        """PolarCode::decode_scl_llr (PolarCode.cpp:130-148). `llr` is [N] or [B, N]; float32 arrays
+        travel as float32 and are widened exactly on the device, anything else is taken as float64."""
+        if isinstance(llr, np.ndarray) and llr.dtype == np.float32:
+            a = np.ascontiguousarray(llr)
+            single = a.ndim == 1
+            a2 = a.reshape(-1, self.N)
+            out = np.zeros((a2.shape[0], self.K), np.uint8)
+            _check(lib().polar_decode_scl_llr_batch_f32(self._h, _p(a2, C.POINTER(C.c_float)), C.c_long(a2.shape[0]),
+                                                        C.c_int(list_size), _p(out, _u8p)))
+            return out[0] if single else out
         a = np.ascontiguousarray(llr, np.float64)
         single = a.ndim == 1
         a2 = a.reshape(-1, self.N)
@@ -260,6 +269,11 @@ class PolarCode:
         _check(lib().polar_decode_scl_llr_batch(self._h, _p(a2, _dp), C.c_long(a2.shape[0]), C.c_int(list_size),
                                                 _p(out, _u8p)))
         return out[0] if single else out
+
+    def decode_scl_llr_dev_f32(self, llr_ptr, B, list_size, out_ptr, pm_ptr=0, stream=None):
+        """Device-resident float32 LLRs [B, N] -> uint8 [B, K]; asynchronous on `stream`."""
+        _check(lib().polar_decode_scl_llr_batch_dev_f32(self._h, C.c_void_p(llr_ptr), C.c_long(B), C.c_int(list_size),
+                                                        C.c_void_p(out_ptr), C.c_void_p(pm_ptr), _stream_ptr(stream)))
 
     def decode_scl_p1(self, p1, p0, list_size):
         """PolarCode::decode_scl_p1 (PolarCode.cpp:110-128)."""

@@ -82,6 +82,7 @@ struct polar_code {
     DevBuf<uint32_t> d_c_scr, d_hist_scr;
     // staging for the host-pointer entry points
     DevBuf<double> d_in;
+    DevBuf<float> d_f32;
     DevBuf<uint8_t> d_out, d_bytes_a, d_bytes_b;
     DevBuf<unsigned long long> d_counter;
     DevBuf<uint64_t> d_sel;
@@ -258,7 +259,7 @@ void polar_destroy(polar_code_t *h) {
     if (h->dev_ready) (void)hipSetDevice(h->device);
     h->d_frozen.release(); h->d_sched.release(); h->d_crcm.release(); h->d_order.release(); h->d_info_rank.release();
     h->d_crc_mask.release(); h->d_tabs.release(); h->d_pre.release(); h->d_llr_scr.release(); h->d_c_scr.release(); h->d_hist_scr.release();
-    h->d_in.release(); h->d_out.release(); h->d_bytes_a.release(); h->d_bytes_b.release();
+    h->d_in.release(); h->d_f32.release(); h->d_out.release(); h->d_bytes_a.release(); h->d_bytes_b.release();
     h->d_counter.release(); h->d_sel.release();
     delete h;
 }
@@ -403,6 +404,35 @@ int polar_decode_scl_llr_batch(polar_code_t *h, const double *llr, long B, int L
 
 int polar_decode_scl_llr(polar_code_t *h, const double *llr, int L, uint8_t *out) {
     return polar_decode_scl_llr_batch(h, llr, 1, L, out);
+}
+
+// single-precision LLRs at the boundary: widened (exactly) to double on the device, then the same path
+int polar_decode_scl_llr_batch_dev_f32(polar_code_t *h, const float *d_llr, long B, int L, uint8_t *d_out,
+                                       double *d_pm, void *stream) {
+    if (!h || !d_llr || !d_out) return fail(POLAR_E_ARG, "NULL argument");
+    if (L < 1 || L > POLAR_MAX_LIST) return fail(POLAR_E_ARG, "list size %d out of range [1, %d]", L, POLAR_MAX_LIST);
+    if (B < 0) return fail(POLAR_E_ARG, "negative batch");
+    if (B == 0) return POLAR_OK;
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    if ((rc = h->d_in.ensure((size_t)B * h->N))) return rc;
+    HIP_TRY(polar_launch_widen(d_llr, h->d_in.p, (size_t)B * h->N, (hipStream_t)stream));
+    return polar_decode_scl_llr_batch_dev(h, h->d_in.p, B, L, d_out, d_pm, stream);
+}
+int polar_decode_scl_llr_batch_f32(polar_code_t *h, const float *llr, long B, int L, uint8_t *out) {
+    if (!h || !llr || !out) return fail(POLAR_E_ARG, "NULL argument");
+    if (B < 0) return fail(POLAR_E_ARG, "negative batch");
+    if (B == 0) return POLAR_OK;
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    if ((rc = h->d_f32.ensure((size_t)B * h->N))) return rc;
+    if ((rc = h->d_out.ensure((size_t)B * h->K))) return rc;
+    HIP_TRY(hipMemcpy(h->d_f32.p, llr, (size_t)B * h->N * sizeof(float), hipMemcpyHostToDevice));
+    rc = polar_decode_scl_llr_batch_dev_f32(h, h->d_f32.p, B, L, h->d_out.p, nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, h->d_out.p, (size_t)B * h->K, hipMemcpyDeviceToHost));
+    return POLAR_OK;
 }
 
 // PolarCode::decode_scl_p1 (PolarCode.cpp:110-128): probability-domain SCL

@@ -55,6 +55,7 @@ struct PolarConstructParams {
     uint8_t *x_scr;              // per-wave scratch [grid][2*N][64]
     unsigned long long *num_err; // [N] device accumulators
 };
+hipError_t polar_launch_widen(const float *src, double *dst, size_t n, hipStream_t st);
 hipError_t polar_launch_mc_front(const PolarConstructParams &p, int grid, hipStream_t st);
 hipError_t polar_launch_mc_genie(const PolarConstructParams &p, int grid, hipStream_t st);
 

@@ -222,3 +222,22 @@ def test_long_codes_and_extreme_parameters(built_lib, oracle_built, n, K, crc, L
     want = o.decode_scl_llr(llr, L)
     got = g.decode_scl_llr(llr, L)
     assert (want == got).all()
+
+
+@pytest.mark.parametrize("n,K,crc,L", [(9, 256, 8, 8), (11, 1024, 16, 32), (6, 20, 3, 1)])
+def test_float32_llr_boundary(built_lib, oracle_built, n, K, crc, L):
+    """the boundary also takes single-precision LLRs; they are widened exactly, so the
+    result is the reference's decode of (double)llr."""
+    import torch
+    o, g = _pair(n, K, crc)
+    B = 40
+    llr, _ = o.synth_llr(515, 0, B, o.snr_sqrt_linear(1.5))
+    f = llr.astype(np.float32)
+    f[0, :4] = [0.0, -0.0, np.float32(1e-30), np.float32(-3e38)]
+    want = o.decode_scl_llr(f.astype(np.float64), L)
+    assert (g.decode_scl_llr(f, L) == want).all()
+    d = torch.tensor(f, device="cuda")
+    out = torch.empty((B, K), dtype=torch.uint8, device="cuda")
+    g.decode_scl_llr_dev_f32(d.data_ptr(), B, L, out.data_ptr())
+    torch.cuda.synchronize()
+    assert (out.cpu().numpy() == want).all()
