@@ -20,6 +20,16 @@ struct P16 {
 };
 
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+// Lane index recomputed on the spot (2 VALU instructions). Everything derived from the lane index is
+// loop-invariant, and with ~190 live values the register allocator parks such invariants in SCRATCH
+// and reloads them in the middle of every leaf step / layer visit (a memory round trip each, with
+// an s_waitcnt vmcnt on the critical path). A volatile asm cannot be hoisted or merged, so values
+// derived from this are short-lived and never spilled.
+__device__ __forceinline__ int lane_id_opaque() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
     unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
     lo = __shfl(lo, src, 64);

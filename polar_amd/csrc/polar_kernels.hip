@@ -154,6 +154,12 @@ __device__ __forceinline__ void softplus_pair(double a, bool skip, const Tabs &t
 #ifndef OCC
 #define OCC 4
 #endif
+// per-phase re-derivation of the lane-dependent invariants (see lane_id_opaque in polar_device.h)
+#define LANE_CTX                                   \
+    const int lane = lane_id_opaque();             \
+    const int lig = lane & (GS - 1);               \
+    const int gbase = lane & ~(GS - 1);            \
+    (void)lig; (void)gbase;
 template <int GS, int LDS_LOG, int PIPE>
 __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_llr_kernel(PolarDecodeParams p) {
     // PIPE=1: one wave per block (8 waves/CU, register double-buffering); PIPE=0: four independent
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     constexpr int G = 64 / GS;
     constexpr int SL = 1 << LDS_LOG;
     const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;                       // wave in block
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave in block (uniform: keeps every per-wave base pointer in SGPRs)
     const int wave_id = blockIdx.x * WPB + wib;             // owns one slice of the global scratch
     const int nwaves = gridDim.x * WPB;
     const int lig = lane & (GS - 1);   // path index l of the reference
@@ -244,6 +250,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
             // recursivelyUpdateC (PolarCode.cpp:457-473) from the layer of size S upwards: X = column 1 of
             // that layer (the S bits just completed by a RIGHT child with node index ph)
             auto update_c = [&](int S, uint32_t X, int ph) {
+                LANE_CTX
                 for (;;) {
                     if (4 * S > N) break;                   // C_0 is never read (PolarCode.cpp writes it, nobody uses it)
                     const int psi = ph >> 1;
@@ -301,8 +308,12 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 if (!PIPE && S >= 8 && 2 * S > SL && lam + 1 <= lam_stop && ((phi >> (sh - 1)) & 1) == 0) {   // (lam+1 is an f-visit)
                     const int H = S / 2;
                     if (active) {
+                        LANE_CTX
                         const bool in_is_ch = (lam == 1);
-                        const bool in_pre = !in_is_ch && pre_cw && 2 * S >= p.prefix_q && phi < 2 * S;
+                        const bool in_pre = !in_is_ch && p.prefix_q > 0 && 2 * S >= p.prefix_q && phi < 2 * S;
+                        // (active lanes are valid ones: codeword g0 + lane / GS)
+                        const double *in0 = in_is_ch ? p.llr + (size_t)(g0 + lane / GS) * N : nullptr;
+                        const double *pre_cw = in_pre ? p.pre + (size_t)(g0 + lane / GS) * (size_t)(N - p.prefix_q + 1) : nullptr;
                         const int pin = (in_is_ch || in_pre) ? 0 : pL.get(sh + 1);
                         const size_t istr = in_pre ? 1 : 64;      // prefix layers are contiguous per codeword
                         const double *gin = in_is_ch ? nullptr : (in_pre ? pre_cw + 1 + (size_t)(N - 4 * S)
@@ -373,6 +384,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 // ds_write on provably-LDS pointers, all inputs of the visit loaded before the first f
                 if (lam > 1 && 2 * S <= SL) {
                     if (active) {
+                        LANE_CTX
                         const double *li = lds_llr + (size_t)(2 * S - 1) * 64 + gbase + pL.get(sh + 1);
                         double *lo = lds_llr + (size_t)(S - 1) * 64 + lane;
                         const uint32_t cb = odd ? (uint32_t)(clsmall >> S) : 0u;
@@ -399,12 +411,15 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     continue;
                 }
                 if (active) {
+                    LANE_CTX
                     // input layer lam-1 (size 2S): 0 = channel LLRs, else scratch/LDS slot
                     const int pin = (lam > 1) ? pL.get(sh + 1) : 0;
                     const double *inp;   // element j at inp[j*istride]
                     size_t istride;
                     const bool in_is_ch = (lam == 1);
-                    const bool in_pre = !in_is_ch && pre_cw && 2 * S >= p.prefix_q && phi < 2 * S;
+                    const bool in_pre = !in_is_ch && p.prefix_q > 0 && 2 * S >= p.prefix_q && phi < 2 * S;
+                    const double *in0 = in_is_ch ? p.llr + (size_t)(g0 + lane / GS) * N : nullptr;
+                    const double *pre_cw = in_pre ? p.pre + (size_t)(g0 + lane / GS) * (size_t)(N - p.prefix_q + 1) : nullptr;
                     constexpr bool in_lds = false;          // (LDS inputs were handled above)
                     istride = 64;
                     if (in_pre) { inp = pre_cw + 1 + (size_t)(N - 4 * S); istride = 1; }
@@ -523,6 +538,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 // leaf by leaf in order (PolarCode.cpp:475-487), and the block's partial sums (Z zeros) are
                 // handed to the layer of size Z exactly as the last leaf's recursivelyUpdateC would.
                 const int Z = 1 << zb;
+                LANE_CTX
                 // one 4-leaf sub-block: values v0..v3 of a size-4 node -> leaves (f,f) (f,g) (g,f) (g,g), then
                 // the metric update of those four leaves in order
                 auto block4 = [&](double v0, double v1, double v2, double v3) {
@@ -577,6 +593,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 continue;
             }
             // ---------------- leaf: frozen / unfrozen ----------------
+            LANE_CTX
+            const u64 below = (1ull << lig) - 1ull;
             const bool frozen = p.frozen[phi] != 0;   // wave-uniform
             unsigned ubit = 0;
             if (frozen) {
