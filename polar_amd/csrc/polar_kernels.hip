@@ -245,8 +245,15 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         }
 
         PROF_DECL
+        // per-leaf control word (frozen flag, rate-0 block size): a SCALAR load through the constant
+        // address space, issued one leaf ahead — as a plain global load it is a vector memory round
+        // trip on the critical path of every leaf
+        typedef const uint32_t __attribute__((address_space(4))) *kconst_u32;
+        const kconst_u32 ctlp = (kconst_u32)(uintptr_t)p.ctl;
+        uint32_t ctl_next = ctlp[phi_start];
         for (int phi = phi_start; phi < N; ++phi) {
             PROF(0)
+            const uint32_t ctl = ctl_next;
             // recursivelyUpdateC (PolarCode.cpp:457-473) from the layer of size S upwards: X = column 1 of
             // that layer (the S bits just completed by a RIGHT child with node index ph)
             auto update_c = [&](int S, uint32_t X, int ph) {
@@ -292,7 +299,11 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 }
             };
             // all-frozen aligned block of 2^zb leaves starting here (host schedule), 0 = ordinary leaf
-            const int zb = p.sched ? (int)p.sched[phi] : 0;
+            const int zb = (int)(ctl >> 1);
+            {
+                const int nphi = phi + (1 << zb);
+                ctl_next = ctlp[nphi < N ? nphi : 0];
+            }
             const int lam_stop = n - zb;
             // ---------------- recursivelyCalcLLR(n, phi): PolarCode.cpp:422-455 ----------------
             const int lam_top = (phi == phi_start && forced_top) ? forced_top : (phi ? (n - __builtin_ctz((unsigned)phi)) : 1);
@@ -595,7 +606,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
             // ---------------- leaf: frozen / unfrozen ----------------
             LANE_CTX
             const u64 below = (1ull << lig) - 1ull;
-            const bool frozen = p.frozen[phi] != 0;   // wave-uniform
+            const bool frozen = (ctl & 1u) != 0;      // wave-uniform
             unsigned ubit = 0;
             if (frozen) {
                 // continuePaths_FrozenBit: PolarCode.cpp:475-487
