@@ -184,8 +184,10 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     unsigned char *wbase = smem + 324 * 8 + (size_t)wib * WAVE_LDS;
     double *lds_llr = reinterpret_cast<double *>(wbase);                       // [(2*SL-1)][64]
     double *sortbuf = lds_llr + (size_t)(2 * SL - 1) * 64;                     // [128]
-    volatile unsigned char *stackv = reinterpret_cast<unsigned char *>(sortbuf + 128);   // [64]
-    volatile unsigned char *srcof = stackv + 64;                               // [64]
+    // (plain pointers, ordered by wave_mem_fence(): a volatile-qualified pointer loses its LDS address
+    // space and every access becomes a system-coherent FLAT operation that waits for all memory)
+    unsigned char *stackv = reinterpret_cast<unsigned char *>(sortbuf + 128);   // [64]
+    unsigned char *srcof = stackv + 64;                                         // [64]
     for (int i = threadIdx.x; i < 322; i += WPB * 64) tabs[i] = p.tabs[i];
     if (WPB > 1) __syncthreads();
     const Tabs tb = {tabs, tabs + 64, tabs + 64 + 129};
@@ -571,27 +573,32 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                         }
                     }
                 };
-                const double *yp = (Z <= SL) ? (lds_llr + (size_t)(Z - 1) * 64 + lane) : (g_llr + (size_t)(Z - 2 * SL) * 64 + lane);
-                if (zb == 3) {
-                    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
-                    if (active) {
+                // (one instantiation per address space of the source: a maybe-LDS-maybe-global pointer would
+                // turn the loads into FLAT instructions that wait for every outstanding memory operation)
+                auto rate0 = [&](const double *yp) {
+                    if (zb == 3) {
+                        double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+                        if (active) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const double lo = yp[(size_t)j * 64], hi = yp[(size_t)(j + 4) * 64];
-                            a[j] = f_node(lo, hi, tb);
-                            b[j] = g_node(lo, hi, 0u);
+                            for (int j = 0; j < 4; ++j) {
+                                const double lo = yp[(size_t)j * 64], hi = yp[(size_t)(j + 4) * 64];
+                                a[j] = f_node(lo, hi, tb);
+                                b[j] = g_node(lo, hi, 0u);
+                            }
                         }
-                    }
-                    block4(a[0], a[1], a[2], a[3]);
-                    block4(b[0], b[1], b[2], b[3]);
-                } else {
-                    double y[4] = {0, 0, 0, 0};
-                    if (active) {
+                        block4(a[0], a[1], a[2], a[3]);
+                        block4(b[0], b[1], b[2], b[3]);
+                    } else {
+                        double y[4] = {0, 0, 0, 0};
+                        if (active) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) y[j] = yp[(size_t)j * 64];
+                            for (int j = 0; j < 4; ++j) y[j] = yp[(size_t)j * 64];
+                        }
+                        block4(y[0], y[1], y[2], y[3]);
                     }
-                    block4(y[0], y[1], y[2], y[3]);
-                }
+                };
+                if (Z <= SL) rate0(lds_llr + (size_t)(Z - 1) * 64 + lane);
+                else rate0(g_llr + (size_t)(Z - 2 * SL) * 64 + lane);
                 const int nu = phi >> zb;                     // node index of the block at its layer
                 if ((nu & 1) == 0) {
                     if (active) clsmall &= ~((((u64)1 << Z) - 1ull) << Z);   // column 0 of that layer := 0
