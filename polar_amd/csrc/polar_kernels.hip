@@ -89,6 +89,32 @@ __device__ __forceinline__ double log_1p2(double m, const Tabs &tb) {    // log(
 __device__ __forceinline__ double h_fn(double x, const Tabs &tb) {       // log1p(e^-x), x >= 0
     return log_1p2(1.0 + exp_neg(x, tb), tb);
 }
+// h(x) - h(y): the two evaluations of an f-node written in lockstep, so that their table reads are
+// issued together (2 LDS round trips per f-node instead of 4) and the two dependent fp64 chains
+// overlap. Same operations and rounding as h_fn(x) - h_fn(y).
+__device__ __forceinline__ double h_diff(double x, double y, const Tabs &tb) {
+    const double kx = __builtin_rint(x * 92.332482616893657), ky = __builtin_rint(y * 92.332482616893657);
+    const int ix = (int)kx, iy = (int)ky;
+    const double tx = tb.T[ix & 63], ty = tb.T[iy & 63];
+    double rx = __builtin_fma(kx, -0.010830424696223417, x), ry = __builtin_fma(ky, -0.010830424696223417, y);
+    rx = __builtin_fma(kx, -2.5728046223276688e-14, rx); ry = __builtin_fma(ky, -2.5728046223276688e-14, ry);
+    double px = rx * (-1.0 / 120.0) + 1.0 / 24.0, py = ry * (-1.0 / 120.0) + 1.0 / 24.0;
+    px = __builtin_fma(px, rx, -1.0 / 6.0); py = __builtin_fma(py, ry, -1.0 / 6.0);
+    px = __builtin_fma(px, rx, 0.5); py = __builtin_fma(py, ry, 0.5);
+    px = __builtin_fma(px, rx, -1.0); py = __builtin_fma(py, ry, -1.0);
+    px = __builtin_fma(px, rx, 1.0); py = __builtin_fma(py, ry, 1.0);
+    const double mx = 1.0 + __builtin_ldexp(tx * px, -(ix >> 6)), my = 1.0 + __builtin_ldexp(ty * py, -(iy >> 6));
+    const double jx = __builtin_rint((mx - 1.0) * 128.0), jy = __builtin_rint((my - 1.0) * 128.0);
+    const int nx = (int)jx, ny = (int)jy;
+    const double rcx = tb.RC[nx], rcy = tb.RC[ny], lcx = tb.LC[nx], lcy = tb.LC[ny];
+    const double qx = (mx - __builtin_fma(jx, 0.0078125, 1.0)) * rcx, qy = (my - __builtin_fma(jy, 0.0078125, 1.0)) * rcy;
+    double ux = qx * (-1.0 / 6.0) + 0.2, uy = qy * (-1.0 / 6.0) + 0.2;
+    ux = __builtin_fma(ux, qx, -0.25); uy = __builtin_fma(uy, qy, -0.25);
+    ux = __builtin_fma(ux, qx, 1.0 / 3.0); uy = __builtin_fma(uy, qy, 1.0 / 3.0);
+    ux = __builtin_fma(ux, qx, -0.5); uy = __builtin_fma(uy, qy, -0.5);
+    ux = __builtin_fma(ux, qx, 1.0); uy = __builtin_fma(uy, qy, 1.0);
+    return __builtin_fma(qx, ux, lcx) - __builtin_fma(qy, uy, lcy);
+}
 __device__ __attribute__((noinline)) double f_literal(double a, double b) {
     return log((exp(a + b) + 1) / (exp(a) + exp(b)));
 }
@@ -105,7 +131,7 @@ __device__ __forceinline__ double f_node(double a, double b, const Tabs &tb) {
         // literal expression is evaluated for those (physically never occurring) elements.
         if (mn < 9.5367431640625e-07) return f_literal(a, b);
         const double base = ((a < 0) != (b < 0)) ? -mn : mn;
-        return base + (h_fn(fabs(a + b), tb) - h_fn(fabs(a - b), tb));
+        return base + h_diff(fabs(a + b), fabs(a - b), tb);
     }
 #endif
     // min-sum branch, PolarCode.cpp:443-445: sgn(a)*sgn(b)*min(|a|,|b|) with sgn(0) = 0. The product
