@@ -142,6 +142,38 @@ __device__ __forceinline__ double f_node(double a, double b, const Tabs &tb) {
     const double r = __hiloint2double(__double2hiint(mn) | sx, __double2loint(mn));
     return (mn == 0.0) ? 0.0 : r;
 }
+// Two f-nodes at once: same results as f_node() twice, but ONE wave-uniform branch around the two exact
+// evaluations, so that their four h() chains sit in one basic block and overlap (a per-node divergent
+// branch serialises the nodes). Used where the nodes are otherwise strictly serial (rate-0 blocks); in
+// the unrolled layer loops it was measured slower (register pressure: -1.4 % fused loop, -25 % LDS visits). Lanes that do not need the exact value compute it on whatever they
+// hold (finite garbage at worst: the table index is masked) and discard it.
+__device__ __forceinline__ void f_node2(double a0, double b0, double a1, double b1, const Tabs &tb, double &r0, double &r1) {
+#ifdef POLAR_EXPERIMENT_NO_EXACT_F
+    r0 = f_node(a0, b0, tb); r1 = f_node(a1, b1, tb);
+#else
+    const double fa0 = fabs(a0), fb0 = fabs(b0), fa1 = fabs(a1), fb1 = fabs(b1);
+    const double mx0 = (fa0 < fb0) ? fb0 : fa0, mn0 = (fb0 < fa0) ? fb0 : fa0;
+    const double mx1 = (fa1 < fb1) ? fb1 : fa1, mn1 = (fb1 < fa1) ? fb1 : fa1;
+    const int s0 = (__double2hiint(a0) ^ __double2hiint(b0)) & (int)0x80000000;
+    const int s1 = (__double2hiint(a1) ^ __double2hiint(b1)) & (int)0x80000000;
+    const double m0 = __hiloint2double(__double2hiint(mn0) | s0, __double2loint(mn0));     // sgn*sgn*min (min-sum value)
+    const double m1 = __hiloint2double(__double2hiint(mn1) | s1, __double2loint(mn1));
+    r0 = (mn0 == 0.0) ? 0.0 : m0;
+    r1 = (mn1 == 0.0) ? 0.0 : m1;
+    const bool e0 = 40 > mx0, e1 = 40 > mx1;
+    if (__any(e0 || e1)) {
+        const double x0 = m0 + h_diff(fabs(a0 + b0), fabs(a0 - b0), tb);
+        const double x1 = m1 + h_diff(fabs(a1 + b1), fabs(a1 - b1), tb);
+        const bool t0 = e0 && mn0 < 9.5367431640625e-07, t1 = e1 && mn1 < 9.5367431640625e-07;
+        if (e0) r0 = x0;
+        if (e1) r1 = x1;
+        if (__any(t0 || t1)) {                    // noise regime (see f_node)
+            if (t0) r0 = f_literal(a0, b0);
+            if (t1) r1 = f_literal(a1, b1);
+        }
+    }
+#endif
+}
 // g-node: PolarCode.cpp:449-450  (1 - 2u)*a + b
 __device__ __forceinline__ double g_node(double a, double b, unsigned u) {
     // (1 - 2u) is +1 or -1 and the product with it is exact: flip the sign bit of a, then add
@@ -202,7 +234,6 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     const int grp = lane / GS;
     const int n = p.n, N = p.N, K = p.K, L = p.L;
     const u64 gmask = (GS == 64) ? ~0ull : ((1ull << GS) - 1ull);
-    const u64 below = (1ull << lig) - 1ull;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *tabs = reinterpret_cast<double *>(smem);                           // T[64] RC[129] LC[129] (+2 pad), per block
@@ -231,7 +262,6 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     for (long g0 = (long)wave_id * G; g0 < p.B; g0 += (long)nwaves * G) {
         const long cw = g0 + grp;
         const bool valid = (cw < p.B);
-        const double *in0 = p.llr + (size_t)(valid ? cw : 0) * N;
 
         // initializeDataStructures + assignInitialPath (PolarCode.cpp:195-272): the inactive
         // stack holds 0..L-1, the first pop (initial path) is L-1.
@@ -583,10 +613,11 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 auto block4 = [&](double v0, double v1, double v2, double v3) {
                     double lf[4] = {0, 0, 0, 0};
                     if (active) {
-                        const double a0 = f_node(v0, v2, tb), a1 = f_node(v1, v3, tb);
+                        double a0, a1;
+                        f_node2(v0, v2, v1, v3, tb, a0, a1);
                         const double b0 = g_node(v0, v2, 0u), b1 = g_node(v1, v3, 0u);
-                        lf[0] = f_node(a0, a1, tb); lf[1] = g_node(a0, a1, 0u);
-                        lf[2] = f_node(b0, b1, tb); lf[3] = g_node(b0, b1, 0u);
+                        f_node2(a0, a1, b0, b1, tb, lf[0], lf[2]);
+                        lf[1] = g_node(a0, a1, 0u); lf[3] = g_node(b0, b1, 0u);
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
