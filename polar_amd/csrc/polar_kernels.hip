@@ -31,9 +31,9 @@
 #include "polar_device.h"
 
 #ifdef POLAR_PROFILE
-#define PROF_DECL u64 prof_acc[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; u64 prof_t = __builtin_readcyclecounter();
+#define PROF_DECL u64 prof_acc[24] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; u64 prof_t = __builtin_readcyclecounter();
 #define PROF(i) { u64 t_ = __builtin_readcyclecounter(); prof_acc[i] += t_ - prof_t; prof_t = t_; }
-#define PROF_OUT if (lane == 0 && p.pm_out) { for (int i_ = 0; i_ < 16; ++i_) atomicAdd((u64 *)p.pm_out + i_, prof_acc[i_]); }
+#define PROF_OUT if (lane == 0 && p.pm_out) { for (int i_ = 0; i_ < 24; ++i_) atomicAdd((u64 *)p.pm_out + i_, prof_acc[i_]); }
 #define PROF_CNT(i, v) { prof_acc[i] += (u64)(v); }
 #else
 #define PROF_DECL
@@ -704,6 +704,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 const double bmin = group_reduce<GS, false>(bl, lane);
                 const bool fastok = (nact == 0) || (nact == L && gmax < bmin);
                 PROF_CNT(8, 1)
+                PROF(16)
                 if (__all(fastok)) {
                     PROF_CNT(9, 1)
                     if (active) {
@@ -711,6 +712,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                         pm = gm;
                         hword |= ubit << (t & 31);
                     }
+                    PROF(17)
                 } else {
                 double pf0 = __builtin_nan(""), pf1 = __builtin_nan("");
                 if (active) {
@@ -750,6 +752,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     // i == lig: my own good fork is never counted against itself (v < mg is false); against my
                     // bad fork the strict part (mg < mb) was counted above, a tie goes to the lower fork index
                     rb += (mg == mb && !goodbit) ? 1 : 0;
+                    PROF(18)
                     // competitive bad forks (few at low SNR, up to all L when garbage paths fill the list):
                     // same scheme from the second half of the exchange buffer, iterations without a
                     // competitive bad fork in any group are skipped on the scalar unit
@@ -783,6 +786,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     // i == lig: my own bad fork against my good fork: mb < mg cannot hold, a tie goes to the
                     // lower fork index (the bad fork has the lower index when the good bit is 1)
                     rg += (cbad && mg == mb && goodbit) ? 1 : 0;
+                    PROF(19)
                     if (full) {
                         const bool sg = active && (rg < L);
                         const bool sbd = cbad && (rb < L);
@@ -839,6 +843,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 }
                 const int src = srcof[lane];
                 const bool is_clone = (src != lig);
+                PROF(20)
                 // PM of the surviving forks: PM + log(1+exp(-+llr)) is the very sum whose negation
                 // was ranked (PolarCode.cpp:580-582, 593, 601)
                 double pm_new = c0 ? -pf0 : -pf1;
@@ -864,6 +869,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 } else {
                     pm = 0.0;   // killPath zeroes the metric (PolarCode.cpp:293-294)
                 }
+                PROF(21)
                 }   // general path
                 // every 32 unfrozen steps the decision word is stored together with the slot (`origin`) that
                 // holds this path's previous word: a linked list per path, walked once at the end, so that
