@@ -179,7 +179,8 @@ int ensure_device(polar_code *h) {
     if ((rc = upload(h->d_crcm, h->crcm))) return rc;
     {   // tables of the fp64 exp/log routines (polar_kernels.hip): T[64], RC[129], LC[129]
         std::vector<double> t(322);
-        for (int j = 0; j < 64; ++j) t[j] = std::exp2(-(double)j / 64.0);
+        // T[f] = 2^(f/64), written as 2 * 2^(-(64-f)/64) (the value the negative-index form selects)
+        for (int j = 0; j < 64; ++j) t[j] = j ? 2.0 * std::exp2(-(double)(64 - j) / 64.0) : 1.0;
         for (int j = 0; j <= 128; ++j) {
             t[64 + j] = 1.0 / (1.0 + (double)j / 128.0);
             t[64 + 129 + j] = std::log1p((double)j / 128.0);

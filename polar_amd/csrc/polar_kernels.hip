@@ -51,8 +51,8 @@ namespace {
 // i.e. an absolute accuracy far below any decision margin. These routines keep ~1e-16 absolute
 // accuracy (the rounding level of the reference's own 1+e^x) at ~1/3 of the instruction count
 // of the libm-style sequence, using two small LDS tables (no division):
-//   exp(-x) = T[k&63] * 2^-(k>>6) * p5(-r),  x = k*ln2/64 + r
-//   log(m)  = LC[j] + log1p((m - c_j)/c_j),   c_j = 1 + j/128, j = rint((m-1)*128)
+//   exp(-x) = T[k&63] * 2^(k>>6) * p5(s),  -x = k*ln2/64 + s  (k <= 0, T[f] = 2^(f/64))
+//   log(m)  = LC[j] + log1p((m - c_j)/c_j),   c_j = 1 + j/128 = m rounded to 7 mantissa bits
 // and the identity  f(a,b) = sgn(a)sgn(b)min(|a|,|b|) + h(|a+b|) - h(|a-b|),  h(x) = log1p(e^-x).
 // Structural exactness is preserved: h(x) == 0 exactly for x >= 36.74 (where the reference's
 // 1+e^-x rounds to 1), f(0,b) == 0 exactly, f is symmetric, log(1+e^x) -> +inf for x > 709.78.
@@ -63,21 +63,29 @@ struct Tabs { const double *T, *RC, *LC; };   // LDS: T[64], RC[129], LC[129]
 // that pair out of every loop, runs out of registers and RELOADS it from scratch (with a full
 // s_waitcnt vmcnt(0)) inside each f-node. mul-by-constant + add-constant needs no VGPR constant.
 __device__ __forceinline__ double exp_neg(double x, const Tabs &tb) {   // e^-x, x >= 0
-    const double kd = __builtin_rint(x * 92.332482616893657);            // 64/ln2
+    // -x = k*ln2/64 + s with k = rint(-x*64/ln2) <= 0:  e^-x = 2^(k>>6) * T[k&63] * e^s,  T[f] = 2^(f/64)
+    // (arithmetic shift / two's-complement mask of the NEGATIVE index: no negation, no second table)
+    const double kd = __builtin_rint(x * -92.332482616893657);           // -64/ln2
     const int k = (int)kd;
-    double r = __builtin_fma(kd, -0.010830424696223417, x);              // ln2/64, high part (low 16 bits zero)
-    r = __builtin_fma(kd, -2.5728046223276688e-14, r);                   // ln2/64, low part
-    double p = r * (-1.0 / 120.0) + 1.0 / 24.0;
-    p = __builtin_fma(p, r, -1.0 / 6.0);
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, -1.0);
-    p = __builtin_fma(p, r, 1.0);
-    return __builtin_ldexp(tb.T[k & 63] * p, -(k >> 6));
+    double s = __builtin_fma(kd, -0.010830424696223417, -x);             // ln2/64, high part (low 16 bits zero)
+    s = __builtin_fma(kd, -2.5728046223276688e-14, s);                   // ln2/64, low part
+    double p = s * (1.0 / 120.0) + 1.0 / 24.0;
+    p = __builtin_fma(p, s, 1.0 / 6.0);
+    p = __builtin_fma(p, s, 0.5);
+    p = __builtin_fma(p, s, 1.0);
+    p = __builtin_fma(p, s, 1.0);
+    return __builtin_ldexp(tb.T[k & 63] * p, k >> 6);
+}
+// table slot of m in [1,2]: m rounded to 7 mantissa bits IS the expansion point c_j = 1 + j/128
+// (integer work on the high word instead of subtract / scale / rint / convert / fma)
+__device__ __forceinline__ int log_slot(double m, double &c) {
+    const int ch = (__double2hiint(m) + 0x1000) & (int)0xFFFFE000;
+    c = __hiloint2double(ch, 0);
+    return (ch - 0x3FF00000) >> 13;                                       // j in [0, 128]
 }
 __device__ __forceinline__ double log_1p2(double m, const Tabs &tb) {    // log(m), m in [1,2]
-    const double jd = __builtin_rint((m - 1.0) * 128.0);
-    const int j = (int)jd;
-    const double c = __builtin_fma(jd, 0.0078125, 1.0);
+    double c;
+    const int j = log_slot(m, c);
     const double q = (m - c) * tb.RC[j];
     double p = q * (-1.0 / 6.0) + 0.2;
     p = __builtin_fma(p, q, -0.25);
@@ -93,21 +101,21 @@ __device__ __forceinline__ double h_fn(double x, const Tabs &tb) {       // log1
 // issued together (2 LDS round trips per f-node instead of 4) and the two dependent fp64 chains
 // overlap. Same operations and rounding as h_fn(x) - h_fn(y).
 __device__ __forceinline__ double h_diff(double x, double y, const Tabs &tb) {
-    const double kx = __builtin_rint(x * 92.332482616893657), ky = __builtin_rint(y * 92.332482616893657);
+    const double kx = __builtin_rint(x * -92.332482616893657), ky = __builtin_rint(y * -92.332482616893657);
     const int ix = (int)kx, iy = (int)ky;
     const double tx = tb.T[ix & 63], ty = tb.T[iy & 63];
-    double rx = __builtin_fma(kx, -0.010830424696223417, x), ry = __builtin_fma(ky, -0.010830424696223417, y);
-    rx = __builtin_fma(kx, -2.5728046223276688e-14, rx); ry = __builtin_fma(ky, -2.5728046223276688e-14, ry);
-    double px = rx * (-1.0 / 120.0) + 1.0 / 24.0, py = ry * (-1.0 / 120.0) + 1.0 / 24.0;
-    px = __builtin_fma(px, rx, -1.0 / 6.0); py = __builtin_fma(py, ry, -1.0 / 6.0);
-    px = __builtin_fma(px, rx, 0.5); py = __builtin_fma(py, ry, 0.5);
-    px = __builtin_fma(px, rx, -1.0); py = __builtin_fma(py, ry, -1.0);
-    px = __builtin_fma(px, rx, 1.0); py = __builtin_fma(py, ry, 1.0);
-    const double mx = 1.0 + __builtin_ldexp(tx * px, -(ix >> 6)), my = 1.0 + __builtin_ldexp(ty * py, -(iy >> 6));
-    const double jx = __builtin_rint((mx - 1.0) * 128.0), jy = __builtin_rint((my - 1.0) * 128.0);
-    const int nx = (int)jx, ny = (int)jy;
+    double sx = __builtin_fma(kx, -0.010830424696223417, -x), sy = __builtin_fma(ky, -0.010830424696223417, -y);
+    sx = __builtin_fma(kx, -2.5728046223276688e-14, sx); sy = __builtin_fma(ky, -2.5728046223276688e-14, sy);
+    double px = sx * (1.0 / 120.0) + 1.0 / 24.0, py = sy * (1.0 / 120.0) + 1.0 / 24.0;
+    px = __builtin_fma(px, sx, 1.0 / 6.0); py = __builtin_fma(py, sy, 1.0 / 6.0);
+    px = __builtin_fma(px, sx, 0.5); py = __builtin_fma(py, sy, 0.5);
+    px = __builtin_fma(px, sx, 1.0); py = __builtin_fma(py, sy, 1.0);
+    px = __builtin_fma(px, sx, 1.0); py = __builtin_fma(py, sy, 1.0);
+    const double mx = 1.0 + __builtin_ldexp(tx * px, ix >> 6), my = 1.0 + __builtin_ldexp(ty * py, iy >> 6);
+    double cx, cy;
+    const int nx = log_slot(mx, cx), ny = log_slot(my, cy);
     const double rcx = tb.RC[nx], rcy = tb.RC[ny], lcx = tb.LC[nx], lcy = tb.LC[ny];
-    const double qx = (mx - __builtin_fma(jx, 0.0078125, 1.0)) * rcx, qy = (my - __builtin_fma(jy, 0.0078125, 1.0)) * rcy;
+    const double qx = (mx - cx) * rcx, qy = (my - cy) * rcy;
     double ux = qx * (-1.0 / 6.0) + 0.2, uy = qy * (-1.0 / 6.0) + 0.2;
     ux = __builtin_fma(ux, qx, -0.25); uy = __builtin_fma(uy, qy, -0.25);
     ux = __builtin_fma(ux, qx, 1.0 / 3.0); uy = __builtin_fma(uy, qy, 1.0 / 3.0);
@@ -122,8 +130,8 @@ __device__ __attribute__((noinline)) double softplus_literal(double x) { return 
 // f-node (check node), exact + min-sum branches: PolarCode.cpp:437-446
 __device__ __forceinline__ double f_node(double a, double b, const Tabs &tb) {
     const double fa = fabs(a), fb = fabs(b);
-    const double mx = (fa < fb) ? fb : fa;
-    const double mn = (fb < fa) ? fb : fa;
+    const double mx = __builtin_fmax(fa, fb);      // (v_max_f64 / v_min_f64 with |.| source modifiers)
+    const double mn = __builtin_fmin(fa, fb);
 #ifndef POLAR_EXPERIMENT_NO_EXACT_F   // (measurement-only build: how much VALU work is NOT the exact f-node)
     if (40 > mx) {
         // |f| <= min(|a|,|b|): when that is within a few orders of the rounding noise (1e-16) the
@@ -152,8 +160,8 @@ __device__ __forceinline__ void f_node2(double a0, double b0, double a1, double 
     r0 = f_node(a0, b0, tb); r1 = f_node(a1, b1, tb);
 #else
     const double fa0 = fabs(a0), fb0 = fabs(b0), fa1 = fabs(a1), fb1 = fabs(b1);
-    const double mx0 = (fa0 < fb0) ? fb0 : fa0, mn0 = (fb0 < fa0) ? fb0 : fa0;
-    const double mx1 = (fa1 < fb1) ? fb1 : fa1, mn1 = (fb1 < fa1) ? fb1 : fa1;
+    const double mx0 = __builtin_fmax(fa0, fb0), mn0 = __builtin_fmin(fa0, fb0);
+    const double mx1 = __builtin_fmax(fa1, fb1), mn1 = __builtin_fmin(fa1, fb1);
     const int s0 = (__double2hiint(a0) ^ __double2hiint(b0)) & (int)0x80000000;
     const int s1 = (__double2hiint(a1) ^ __double2hiint(b1)) & (int)0x80000000;
     const double m0 = __hiloint2double(__double2hiint(mn0) | s0, __double2loint(mn0));     // sgn*sgn*min (min-sum value)
