@@ -132,23 +132,21 @@ __device__ __forceinline__ double f_node(double a, double b, const Tabs &tb) {
     const double fa = fabs(a), fb = fabs(b);
     const double mx = __builtin_fmax(fa, fb);      // (v_max_f64 / v_min_f64 with |.| source modifiers)
     const double mn = __builtin_fmin(fa, fb);
+    // sgn(a)*sgn(b)*min(|a|,|b|) (PolarCode.cpp:443-445, sgn(0) = 0): the magnitude with the XOR of the
+    // two sign bits, done on the high word instead of int->double conversions and multiplies; it is
+    // also the leading term of the exact expression below
+    const int sx = (__double2hiint(a) ^ __double2hiint(b)) & (int)0x80000000;
+    const double ms = __hiloint2double(__double2hiint(mn) | sx, __double2loint(mn));
 #ifndef POLAR_EXPERIMENT_NO_EXACT_F   // (measurement-only build: how much VALU work is NOT the exact f-node)
     if (40 > mx) {
         // |f| <= min(|a|,|b|): when that is within a few orders of the rounding noise (1e-16) the
         // reference's result IS its rounding noise (e.g. exactly 0 once e^a, e^b round to 1), so the
         // literal expression is evaluated for those (physically never occurring) elements.
         if (mn < 9.5367431640625e-07) return f_literal(a, b);
-        const double base = ((a < 0) != (b < 0)) ? -mn : mn;
-        return base + h_diff(fabs(a + b), fabs(a - b), tb);
+        return ms + h_diff(fabs(a + b), fabs(a - b), tb);
     }
 #endif
-    // min-sum branch, PolarCode.cpp:443-445: sgn(a)*sgn(b)*min(|a|,|b|) with sgn(0) = 0. The product
-    // of two signs in {-1,0,1} times a magnitude is that magnitude with the XOR of the sign bits, or
-    // +0 when an operand is zero — done on the high words instead of two int->double conversions
-    // and two multiplies.
-    const int sx = (__double2hiint(a) ^ __double2hiint(b)) & (int)0x80000000;
-    const double r = __hiloint2double(__double2hiint(mn) | sx, __double2loint(mn));
-    return (mn == 0.0) ? 0.0 : r;
+    return (mn == 0.0) ? 0.0 : ms;     // min-sum branch
 }
 // Two f-nodes at once: same results as f_node() twice, but ONE wave-uniform branch around the two exact
 // evaluations, so that their four h() chains sit in one basic block and overlap (a per-node divergent
