@@ -86,6 +86,7 @@ struct polar_code {
     DevBuf<float> d_f32;
     DevBuf<uint8_t> d_out, d_bytes_a, d_bytes_b;
     DevBuf<unsigned long long> d_counter;
+    DevBuf<unsigned int> d_work;
     DevBuf<uint64_t> d_sel;
     // tuning
     int waves_per_cu = 0, lds_log = 0, pipe = -1;
@@ -265,7 +266,7 @@ void polar_destroy(polar_code_t *h) {
     h->d_frozen.release(); h->d_sched.release(); h->d_ctl.release(); h->d_crcm.release(); h->d_order.release(); h->d_info_rank.release();
     h->d_crc_mask.release(); h->d_tabs.release(); h->d_pre.release(); h->d_llr_scr.release(); h->d_c_scr.release(); h->d_hist_scr.release();
     h->d_in.release(); h->d_f32.release(); h->d_out.release(); h->d_bytes_a.release(); h->d_bytes_b.release();
-    h->d_counter.release(); h->d_sel.release();
+    h->d_counter.release(); h->d_sel.release(); h->d_work.release();
     delete h;
 }
 
@@ -384,6 +385,9 @@ int polar_decode_scl_llr_batch_dev_ev(polar_code_t *h, const double *d_llr, long
         p.pre = h->d_pre.p;
     }
     p.llr_scr = h->d_llr_scr.p; p.c_scr = h->d_c_scr.p; p.hist_scr = h->d_hist_scr.p;
+    if ((rc = h->d_work.ensure(1))) return rc;
+    p.work = h->d_work.p;
+    HIP_TRY(hipMemsetAsync(p.work, 0, sizeof(unsigned int), (hipStream_t)stream));
     if (p.prefix_q) HIP_TRY(polar_launch_prefix(p, (hipStream_t)stream));
     if (ev_start) HIP_TRY(hipEventRecord((hipEvent_t)ev_start, (hipStream_t)stream));
     HIP_TRY(polar_launch_decode_llr(p, gs, lds_log, pipe, grid, (hipStream_t)stream));
@@ -462,7 +466,7 @@ int polar_decode_scl_p1_batch(polar_code_t *h, const double *p1, const double *p
     HIP_TRY(hipMemcpy(h->d_in.p + (size_t)B * N, p0, (size_t)B * N * sizeof(double), hipMemcpyHostToDevice));
     PolarDecodeParams p;
     p.n = h->n; p.N = N; p.K = h->K; p.crc = h->crc; p.L = L; p.W = h->W; p.B = B;
-    p.prefix_q = 0; p.prefix_len = 0; p.sched = nullptr; p.ctl = nullptr; p.pre = nullptr;
+    p.prefix_q = 0; p.prefix_len = 0; p.sched = nullptr; p.ctl = nullptr; p.pre = nullptr; p.work = nullptr;
     p.llr = h->d_in.p; p.p0 = h->d_in.p + (size_t)B * N; p.out = h->d_out.p; p.pm_out = nullptr;
     p.frozen = h->d_frozen.p; p.info_rank = h->d_info_rank.p; p.crc_mask = h->d_crc_mask.p; p.tabs = h->d_tabs.p;
     p.llr_scr = h->d_llr_scr.p; p.c_scr = h->d_c_scr.p; p.hist_scr = h->d_hist_scr.p;

@@ -16,6 +16,7 @@ struct PolarDecodeParams {
     const uint8_t *frozen;       // [N] device
     const uint8_t *sched;        // [N] device or nullptr: log2 size of the all-frozen aligned block starting at phi (0, 2 or 3)
     const uint32_t *ctl;         // [N] device: per-leaf control word of the LLR kernel = frozen | sched << 1 (scalar-loaded)
+    unsigned int *work;          // device counter (zeroed before the launch): dynamic hand-out of codeword groups after a wave's first one
     const uint16_t *info_rank;   // [K+crc] device: rank of order[beta] among the unfrozen positions
     const uint32_t *crc_mask;    // [crc][W] device: parity masks over unfrozen ranks (check bit included)
     const double *tabs;          // [322] device: T[64] = 2^(-j/64), RC[129] = 1/(1+j/128), LC[129] = log(1+j/128)

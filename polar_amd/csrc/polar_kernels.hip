@@ -265,7 +265,10 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     uint32_t *g_horg = g_hist + (size_t)p.W * 64;                              // link to the previous word's slot
     uint32_t *g_tb = g_horg + (size_t)p.W * 64;                                // winner's words, per-lane copy
 
-    for (long g0 = (long)wave_id * G; g0 < p.B; g0 += (long)nwaves * G) {
+    // Work distribution: a wave's first group of codewords is its own index, every further one comes
+    // from a device counter. Waves do not take equally long (per-wave time spreads by ~ +-15 %), and with
+    // a static stride the launch ends when the unluckiest wave has finished ALL its groups.
+    for (long g0 = (long)wave_id * G; g0 < p.B;) {
         const long cw = g0 + grp;
         const bool valid = (cw < p.B);
 
@@ -965,6 +968,14 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
             }
         }
         wave_mem_fence();
+        // next group
+        if (p.work) {
+            unsigned nxt = 0;
+            if (lane == 0) nxt = atomicAdd(p.work, 1u);
+            g0 = ((long)nwaves + (long)__builtin_amdgcn_readfirstlane((int)nxt)) * G;
+        } else {
+            g0 += (long)nwaves * G;
+        }
     }  // codeword groups
 }
 
