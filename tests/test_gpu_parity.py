@@ -241,3 +241,17 @@ def test_float32_llr_boundary(built_lib, oracle_built, n, K, crc, L):
     g.decode_scl_llr_dev_f32(d.data_ptr(), B, L, out.data_ptr())
     torch.cuda.synchronize()
     assert (out.cpu().numpy() == want).all()
+
+
+@pytest.mark.parametrize("n,K,crc,L,B", [(6, 30, 4, 32, 3 * 8192 + 17), (5, 16, 0, 8, 2 * 32768 + 5), (7, 64, 8, 64, 2 * 4096 + 3)])
+def test_more_codewords_than_resident_waves(built_lib, oracle_built, n, K, crc, L, B):
+    """Batches larger than one round of the persistent grid (256 CUs x 16 waves x 64/GS codewords):
+    the groups after a wave's first one are handed out by a device counter, in no fixed order — every
+    codeword must still be decoded exactly once, bit-exactly, at its own output position."""
+    o, g = _pair(n, K, crc)
+    llr, _ = o.synth_llr(4242, 0, B, o.snr_sqrt_linear(1.0))
+    got = g.decode_scl_llr(llr, L)
+    want = o.decode_scl_llr(llr, L)
+    bad = np.nonzero((want != got).any(axis=1))[0]
+    assert bad.size == 0, (bad.size, bad[:8])
+    assert (g.decode_scl_llr(llr, L) == got).all()        # and reproducibly so
