@@ -131,6 +131,7 @@ def main():
     achieved = (B * alg_bytes_per_cw) / kern_avg_s / 1e9
     cnt = counters.cpu().numpy()
 
+    traffic, prof = traffic_from_profile(args, B)
     res = {
         "metric": "codewords/s (N=2048 K=1024 L=32 LLR-SCL)",
         "value": value,
@@ -158,11 +159,16 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic_from_profile(args, B),
+            "traffic": traffic,
             "kernel_ms_avg": kern_avg_s * 1e3,
             "algorithmic_bytes_per_codeword": alg_bytes_per_cw,
             "algorithmic_bytes_per_launch": B * alg_bytes_per_cw,
             "node_evals_per_s": (B * L * N * code.n) / kern_avg_s,
+            # the resources this kernel is really bounded by: measured HBM bytes of the
+            # committed PMC profile over the LIVE kernel time, and the profile's fp64 VALU occupancy
+            "traffic_rate_GBps": (traffic / kern_avg_s / 1e9) if traffic else None,
+            "traffic_frac_of_peak": (traffic / kern_avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "valu_busy_frac_in_profile": prof.get("valu_busy_frac_in_profile"),
         },
     }
 
@@ -184,10 +190,10 @@ def traffic_from_profile(args, B):
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         c = t["config"]
         if (c["n"], c["K"], c["crc"], c["L"], c["batch"]) == (args.n, args.K, args.crc, args.L, B):
-            return t["traffic_bytes_per_launch"]
+            return t["traffic_bytes_per_launch"], t
     except Exception:
         pass
-    return None
+    return None, {}
 
 
 def cpu_baseline(args, code, llr, out):

@@ -14,5 +14,11 @@ out = {"config": {"n": n, "K": K, "crc": crc, "L": L, "batch": batch},
        "write_bytes": d["hbm_traffic_per_launch"]["write_bytes"],
        "kernel_avg_ns_in_profile": d["kernel_time"]["avg_ns"],
        "source": src, "command": d["command"]}
+c = d.get("counters", {})
+if "GRBM_GUI_ACTIVE" in c and "SQ_ACTIVE_INST_VALU" in c:
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_* VALU activity is in quad-cycles over 1024 SIMDs
+    cyc = c["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0
+    out["shader_clock_ghz_in_profile"] = cyc / d["kernel_time"]["avg_ns"]
+    out["valu_busy_frac_in_profile"] = c["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] * 4.0 / (1024.0 * cyc)
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)
 print(out)
