@@ -61,8 +61,9 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from polar_amd import build
-    if rank == 0:
+    if rank == 0 and not os.environ.get("POLAR_AMD_LIB"):
         build.build()            # in-tree .so normally travels prebuilt; only one rank may compile
+                                 # (an explicit POLAR_AMD_LIB — A/B runs — is used as it is)
     if dist:
         dist.barrier()
     import polar_amd
