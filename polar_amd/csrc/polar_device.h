@@ -56,6 +56,29 @@ __device__ __forceinline__ double group_reduce(double v, int lane) {
     if (GS >= 64) v = op(v, __shfl(v, lane ^ 32, 64));
     return v;
 }
+// 32-bit unsigned max/min over each group of GS lanes with DPP only (no LDS): the butterfly stages
+// inside a row of 16 leave the row's result in every lane; for GS = 32 / 64 the row_bcast15 / row_bcast31
+// controls (gfx9) carry it into the following rows, so the GROUP result is valid in the last row of
+// each group only: lanes selected by group_result_rows<GS>().
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWMASK, 0xF, false);
+}
+template <int GS, bool MAX>
+__device__ __forceinline__ unsigned group_reduce_u32(unsigned v) {
+    auto op = [](unsigned a, unsigned b) { return MAX ? ((b > a) ? b : a) : ((b < a) ? b : a); };
+    if (GS >= 2) v = op(v, dpp_u32<0xB1, 0xF>(v));
+    if (GS >= 4) v = op(v, dpp_u32<0x4E, 0xF>(v));
+    if (GS >= 8) v = op(v, dpp_u32<0x141, 0xF>(v));
+    if (GS >= 16) v = op(v, dpp_u32<0x140, 0xF>(v));
+    if (GS >= 32) v = op(v, dpp_u32<0x142, 0xA>(v));     // row_bcast15: rows 1, 3 <- lane 15 of rows 0, 2
+    if (GS >= 64) v = op(v, dpp_u32<0x143, 0xC>(v));     // row_bcast31: rows 2, 3 <- lane 31
+    return v;
+}
+template <int GS>
+__device__ __forceinline__ constexpr u64 group_result_rows() {
+    return GS <= 16 ? ~0ull : (GS == 32 ? 0xFFFF0000FFFF0000ull : 0xFFFF000000000000ull);
+}
 __device__ __forceinline__ void wave_mem_fence() {
     // lanes of one wave exchange data through LDS/global: keep the compiler from caching or
     // reordering across this point (hardware executes a wave's memory ops in order)

@@ -709,12 +709,29 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     gm = pm + sneg;
                     bl = (pm + al) * 0.99999999999909050530;
                 }
-                const double gmax = group_reduce<GS, true>(gm, lane);
-                const double bmin = group_reduce<GS, false>(bl, lane);
-                const bool fastok = (nact == 0) || (nact == L && gmax < bmin);
+                // cheap sufficient test first: the metrics are non-negative doubles, so their HIGH words
+                // order like unsigned integers; max / min of those over the group cost one DPP-fused integer
+                // instruction per stage and no LDS traffic. Distinct high words decide gmax < bmin for
+                // certain; only when they collide (|gmax - bmin| < 2^-20 relative) or the test fails are the
+                // exact fp64 reductions run.
+                bool fast;
+                {
+                    unsigned gh = active ? (unsigned)__double2hiint(gm) : 0u;
+                    unsigned bh = active ? (unsigned)__double2hiint(bl) : 0xFFFFFFFFu;
+                    gh = group_reduce_u32<GS, true>(gh);
+                    bh = group_reduce_u32<GS, false>(bh);
+                    const bool ok = (nact == 0) || (nact == L && gh < bh);
+                    fast = ((__ballot(ok) | ~group_result_rows<GS>()) == ~0ull);
+                }
+                double gmax = 0.0;
+                if (!fast) {
+                    gmax = group_reduce<GS, true>(gm, lane);
+                    const double bmin = group_reduce<GS, false>(bl, lane);
+                    fast = __all((nact == 0) || (nact == L && gmax < bmin));
+                }
                 PROF_CNT(8, 1)
                 PROF(16)
-                if (__all(fastok)) {
+                if (fast) {
                     PROF_CNT(9, 1)
                     if (active) {
                         ubit = (leaf < 0) ? 1u : 0u;
