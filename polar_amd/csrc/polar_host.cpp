@@ -76,7 +76,7 @@ struct polar_code {
     // device
     bool dev_ready = false;
     int device = -1, num_cu = 0;
-    DevBuf<uint8_t> d_frozen, d_crcm, d_sched;
+    DevBuf<uint8_t> d_frozen, d_crcm;
     DevBuf<uint16_t> d_order, d_info_rank;
     DevBuf<uint32_t> d_crc_mask, d_ctl;
     DevBuf<double> d_llr_scr, d_tabs, d_pre;
@@ -172,7 +172,6 @@ int ensure_device(polar_code *h) {
     h->num_cu = prop.multiProcessorCount;
     int rc;
     if ((rc = upload(h->d_frozen, h->frozen))) return rc;
-    if ((rc = upload(h->d_sched, h->sched))) return rc;
     if ((rc = upload(h->d_ctl, h->ctl))) return rc;
     if ((rc = upload(h->d_order, h->order))) return rc;
     if ((rc = upload(h->d_info_rank, h->info_rank))) return rc;
@@ -263,7 +262,7 @@ int polar_create_explicit(int n, int K, int crc, const uint8_t *frozen, const ui
 void polar_destroy(polar_code_t *h) {
     if (!h) return;
     if (h->dev_ready) (void)hipSetDevice(h->device);
-    h->d_frozen.release(); h->d_sched.release(); h->d_ctl.release(); h->d_crcm.release(); h->d_order.release(); h->d_info_rank.release();
+    h->d_frozen.release(); h->d_ctl.release(); h->d_crcm.release(); h->d_order.release(); h->d_info_rank.release();
     h->d_crc_mask.release(); h->d_tabs.release(); h->d_pre.release(); h->d_llr_scr.release(); h->d_c_scr.release(); h->d_hist_scr.release();
     h->d_in.release(); h->d_f32.release(); h->d_out.release(); h->d_bytes_a.release(); h->d_bytes_b.release();
     h->d_counter.release(); h->d_sel.release(); h->d_work.release();
@@ -378,7 +377,7 @@ int polar_decode_scl_llr_batch_dev_ev(polar_code_t *h, const double *d_llr, long
     }
     p.llr = d_llr; p.p0 = nullptr; p.out = d_out; p.pm_out = d_pm;
     p.frozen = h->d_frozen.p; p.info_rank = h->d_info_rank.p; p.crc_mask = h->d_crc_mask.p; p.tabs = h->d_tabs.p;
-    p.sched = h->d_sched.p; p.ctl = h->d_ctl.p;
+    p.ctl = h->d_ctl.p;
     p.pre = nullptr;
     if (p.prefix_q) {
         if ((rc = h->d_pre.ensure((size_t)B * (size_t)(h->N - p.prefix_q + 1)))) return rc;
@@ -466,7 +465,7 @@ int polar_decode_scl_p1_batch(polar_code_t *h, const double *p1, const double *p
     HIP_TRY(hipMemcpy(h->d_in.p + (size_t)B * N, p0, (size_t)B * N * sizeof(double), hipMemcpyHostToDevice));
     PolarDecodeParams p;
     p.n = h->n; p.N = N; p.K = h->K; p.crc = h->crc; p.L = L; p.W = h->W; p.B = B;
-    p.prefix_q = 0; p.prefix_len = 0; p.sched = nullptr; p.ctl = nullptr; p.pre = nullptr; p.work = nullptr;
+    p.prefix_q = 0; p.prefix_len = 0; p.ctl = nullptr; p.pre = nullptr; p.work = nullptr;
     p.llr = h->d_in.p; p.p0 = h->d_in.p + (size_t)B * N; p.out = h->d_out.p; p.pm_out = nullptr;
     p.frozen = h->d_frozen.p; p.info_rank = h->d_info_rank.p; p.crc_mask = h->d_crc_mask.p; p.tabs = h->d_tabs.p;
     p.llr_scr = h->d_llr_scr.p; p.c_scr = h->d_c_scr.p; p.hist_scr = h->d_hist_scr.p;
