@@ -72,6 +72,13 @@ def test_argument_validation(built_lib):
         with pytest.raises(polar_amd.PolarError):
             g.decode_scl_llr(np.zeros(32), badL)
     assert abs(g.snr_sqrt_linear(2.0) - 10 ** 0.1 * np.sqrt(0.5)) < 1e-12
+    # Monte-Carlo construction entry point: arguments are checked before any device work
+    for bad in (dict(n=0), dict(n=16), dict(cons=9), dict(cons="qam16"), dict(runs=-1)):
+        with pytest.raises(polar_amd.PolarError):
+            polar_amd.mc_construction(bad.get("n", 5), 1.0, bad.get("runs", 10), bad.get("cons", "bpsk"))
+    assert (polar_amd.mc_construction(5, 1.0, 0, "bpsk") == 0).all()          # zero runs: nothing to do, no device needed
+    with pytest.raises(polar_amd.PolarError):
+        g.decode_scl_llr(np.zeros(32, np.float32), 0)
 
 
 @pytest.mark.skipif(_have_gpu(), reason="only meaningful on a box without a GPU")
@@ -82,6 +89,10 @@ def test_no_cpu_fallback(built_lib):
         g.decode_scl_llr(np.zeros(32), 4)
     with pytest.raises(polar_amd.PolarError):
         g.encode(np.zeros(16, np.uint8))
+    with pytest.raises(polar_amd.PolarError, match="no HIP device|no CPU"):
+        polar_amd.mc_construction(5, 1.0, 10, "bpsk")
+    with pytest.raises(polar_amd.PolarError, match="no HIP device|no CPU"):
+        g.decode_scl_llr(np.zeros(32, np.float32), 4)
 
 
 def test_product_does_not_reference_oracle():
