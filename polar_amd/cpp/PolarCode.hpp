@@ -68,6 +68,15 @@ public:
         check(polar_decode_scl_llr_batch(_h, llr.data(), B, list_size, out.data()));
         return out;
     }
+    // single-precision LLRs (B codewords back to back): widened exactly on the device
+    std::vector<uint8_t> decode_scl_llr_batch(const std::vector<float> &llr, uint16_t list_size) {
+        need(llr.size() % _block_length == 0, "decode_scl_llr_batch: size must be a multiple of block_length");
+        const long B = (long)(llr.size() / _block_length);
+        std::vector<uint8_t> out((size_t)B * _info_length);
+        check(polar_decode_scl_llr_batch_f32(_h, llr.data(), B, list_size, out.data()));
+        return out;
+    }
+
     // PolarCode.cpp:658: bler[list_index][ebno_index]; reference constants max_err=100, max_runs=1000
     std::vector<std::vector<double>> get_bler_quick(std::vector<double> ebno_vec, std::vector<uint8_t> list_size,
                                                     long max_runs = 1000, long max_err = 100, uint64_t seed = 1,
