@@ -67,6 +67,7 @@ def build(force=False, verbose=False, profile=False):
                 cmd.insert(1, "-DPOLAR_PROFILE")
             for d in os.environ.get("POLAR_DEFS", "").split():
                 cmd.insert(1, "-D" + d)
+            cmd[1:1] = os.environ.get("POLAR_HIPCC_FLAGS", "").split()    # A/B experiments with compiler options
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
