@@ -17,8 +17,14 @@ import oracle_lib
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 libc = C.CDLL(None)
 total_bad = 0
-for (n, K, crc, L, ebno, B) in [(11, 1024, 16, 32, 1.0, 6144), (11, 1024, 16, 32, 2.0, 6144), (11, 1024, 16, 4, 1.0, 16384),
-                                (11, 1024, 0, 1, 1.5, 65536), (10, 512, 0, 8, 1.0, 16384), (9, 256, 8, 32, 0.5, 8192)]:
+SETS = {
+    "1": [(11, 1024, 16, 32, 1.0, 6144), (11, 1024, 16, 32, 2.0, 6144), (11, 1024, 16, 4, 1.0, 16384),
+          (11, 1024, 0, 1, 1.5, 65536), (10, 512, 0, 8, 1.0, 16384), (9, 256, 8, 32, 0.5, 8192)],
+    # other rates / sizes / list sizes, high and very low SNR
+    "2": [(11, 1024, 16, 32, 3.0, 4096), (11, 1024, 16, 32, -1.0, 3072), (12, 2048, 16, 8, 1.5, 4096), (10, 768, 8, 16, 3.0, 8192),
+          (8, 64, 0, 32, 0.0, 16384), (11, 512, 24, 5, 0.5, 8192), (13, 4096, 0, 2, 2.0, 2048), (11, 1536, 11, 64, 3.5, 2048)],
+}
+for (n, K, crc, L, ebno, B) in SETS[os.environ.get("STRESS_SET", "1")]:
     B = int(B * scale)
     libc.srand(1)
     g = polar_amd.PolarCode(n, K, 0.32, crc)
