@@ -122,7 +122,8 @@ int polar_count_errors_dev(polar_code_t *h, const uint8_t *d_a, const uint8_t *d
  * (one noise vector shared by every (L, Eb/N0); ascending Eb/N0 with "decoded at a lower
  * Eb/N0 => counted, not simulated", :728-742); the early stop `num_err > max_err` (:725)
  * is evaluated between batches of `batch` trials (batch = 1 reproduces the reference's
- * per-run granularity).  Reference defaults: max_runs = 1000, max_err = 100 (:661-662).
+ * per-run granularity; batch = 0 picks min(max_runs, 65536)).  Reference defaults:
+ * max_runs = 1000, max_err = 100 (:661-662).
  * Sharding: this rank simulates trials t with t % world == rank (counter-based RNG makes
  * the union independent of `world`); err/run accumulators are returned so the caller can
  * all-reduce them (RCCL) between batches: see polar_mc_* below for the step-wise form. */

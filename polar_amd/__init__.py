@@ -350,7 +350,7 @@ class PolarCode:
         Ls = np.ascontiguousarray(list_size_vec, np.uint8)
         out = np.zeros((len(Ls), len(ebno)), np.float64)
         if batch is None:
-            batch = max_runs
+            batch = 0          # library default: min(max_runs, 65536)
         _check(lib().polar_get_bler_quick(self._h, _p(ebno, _dp), C.c_int(len(ebno)), _p(Ls, _u8p), C.c_int(len(Ls)),
                                           C.c_long(max_runs), C.c_long(max_err), C.c_uint64(seed), C.c_long(batch),
                                           _p(out, _dp)))

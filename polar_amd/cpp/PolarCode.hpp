@@ -83,7 +83,7 @@ public:
                                                     long batch = 0) {
         std::vector<double> flat(ebno_vec.size() * list_size.size());
         check(polar_get_bler_quick(_h, ebno_vec.data(), (int)ebno_vec.size(), list_size.data(), (int)list_size.size(),
-                                   max_runs, max_err, seed, batch > 0 ? batch : max_runs, flat.data()));
+                                   max_runs, max_err, seed, batch, flat.data()));   // batch 0: library default
         std::vector<std::vector<double>> bler(list_size.size(), std::vector<double>(ebno_vec.size()));
         for (size_t l = 0; l < list_size.size(); ++l)
             for (size_t e = 0; e < ebno_vec.size(); ++e) bler[l][e] = flat[l * ebno_vec.size() + e];

@@ -700,7 +700,8 @@ int polar_mc_construction(int n, int constellation, double design_snr_db, uint64
 int polar_get_bler_quick(polar_code_t *h, const double *ebno, int n_e, const uint8_t *Ls, int n_L,
                          long max_runs, long max_err, uint64_t seed, long batch, double *bler_out) {
     if (!h || !ebno || !Ls || !bler_out) return fail(POLAR_E_ARG, "NULL argument");
-    if (n_e <= 0 || n_L <= 0 || max_runs <= 0 || batch <= 0) return fail(POLAR_E_ARG, "bad sizes");
+    if (n_e <= 0 || n_L <= 0 || max_runs <= 0 || batch < 0) return fail(POLAR_E_ARG, "bad sizes");
+    if (batch == 0) batch = std::min<long>(max_runs, 65536);       // default: bounded device memory, several rounds of waves
     const int P = n_e * n_L;
     std::vector<uint64_t> err(P, 0), run(P, 0);
     std::vector<uint8_t> en(P, 1);
