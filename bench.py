@@ -25,9 +25,9 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
-# what a pure streaming kernel with the decoder's access structure reaches on the same GPU
-# (tools/rowsize_microbench.hip, profiles/r01/l_rowsize_microbench.txt)
-STREAM_PATTERN_GBS = 5200.0
+# rate at which the decode kernel itself streams its state with the exact f-node compiled out
+# (measurement build POLAR_EXPERIMENT_NO_EXACT_F): the traffic floor of this design
+STREAM_PATTERN_GBS = 5870.0
 
 
 def main():
@@ -172,7 +172,7 @@ def main():
             # committed PMC profile over the LIVE kernel time, and the profile's fp64 VALU occupancy
             "traffic_rate_GBps": (traffic / kern_avg_s / 1e9) if traffic else None,
             "traffic_frac_of_peak": (traffic / kern_avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-            "traffic_frac_of_streaming_pattern_ceiling": (traffic / kern_avg_s / 1e9 / STREAM_PATTERN_GBS) if traffic else None,
+            "traffic_frac_of_traffic_floor_rate": (traffic / kern_avg_s / 1e9 / STREAM_PATTERN_GBS) if traffic else None,
             "valu_busy_frac_in_profile": prof.get("valu_busy_frac_in_profile"),
         },
     }
