@@ -163,6 +163,11 @@ int polar_mc_construction(int n, int constellation, double design_snr_db, uint64
 
 /* tuning knobs (0 = default): waves resident per CU and LDS-resident layer exponent */
 int polar_set_tuning(polar_code_t *h, int waves_per_cu, int lds_log);
+/* node arithmetic of decode_scl_llr: 0 = automatic (exp-domain kernel for list sizes >= 5, LLR-domain kernel
+ * below), 1 = LLR-domain kernel only (table-driven exp/log1p f-node, the round-1 path), 2 = exp-domain kernel
+ * (f-node = one division; codewords it cannot decide safely are flagged on the device and decoded again by the
+ * LLR-domain kernel in the same call). Decoded bits are the reference's in every mode. */
+int polar_set_mode(polar_code_t *h, int mode);
 
 #ifdef __cplusplus
 }

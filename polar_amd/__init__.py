@@ -238,6 +238,10 @@ class PolarCode:
     def set_tuning(self, waves_per_cu=0, lds_log=0):
         _check(lib().polar_set_tuning(self._h, C.c_int(waves_per_cu), C.c_int(lds_log)))
 
+    def set_mode(self, mode=0):
+        """Node arithmetic of decode_scl_llr: 0 automatic, 1 LLR-domain kernel, 2 exp-domain kernel (+ fallback pass)."""
+        _check(lib().polar_set_mode(self._h, C.c_int(mode)))
+
     def snr_sqrt_linear(self, ebno_db):
         return lib().polar_snr_sqrt_linear(self._h, C.c_double(ebno_db))
 

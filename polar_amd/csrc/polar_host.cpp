@@ -88,6 +88,12 @@ struct polar_code {
     DevBuf<unsigned long long> d_counter;
     DevBuf<unsigned int> d_work;
     DevBuf<uint64_t> d_sel;
+    // exp-domain fast path: stored-form channel values, guard flags, fallback work list + its length
+    DevBuf<double> d_ech;
+    DevBuf<uint8_t> d_flags;
+    DevBuf<uint32_t> d_list;
+    DevBuf<unsigned int> d_count;
+    int mode = 0;                    // 0 auto, 1 LLR-domain kernel only, 2 exp-domain kernel + fallback pass
     // tuning
     int waves_per_cu = 0, lds_log = 0, pipe = -1;
     bool prefix_on = true;
@@ -266,6 +272,7 @@ void polar_destroy(polar_code_t *h) {
     h->d_crc_mask.release(); h->d_tabs.release(); h->d_pre.release(); h->d_llr_scr.release(); h->d_c_scr.release(); h->d_hist_scr.release();
     h->d_in.release(); h->d_f32.release(); h->d_out.release(); h->d_bytes_a.release(); h->d_bytes_b.release();
     h->d_counter.release(); h->d_sel.release(); h->d_work.release();
+    h->d_ech.release(); h->d_flags.release(); h->d_list.release(); h->d_count.release();
     delete h;
 }
 
@@ -315,7 +322,15 @@ int polar_set_tuning(polar_code_t *h, int waves_per_cu, int lds_log) {
     return POLAR_OK;
 }
 
+int polar_set_mode(polar_code_t *h, int mode) {
+    if (!h) return fail(POLAR_E_ARG, "NULL handle");
+    if (mode < 0 || mode > 2) return fail(POLAR_E_ARG, "mode must be 0 (auto), 1 (LLR-domain) or 2 (exp-domain)");
+    h->mode = mode;
+    return POLAR_OK;
+}
+
 double polar_snr_sqrt_linear(const polar_code_t *h, double ebno_db) {   // PolarCode.cpp:744-745
+    if (!h) return NAN;
     return std::pow(10.0f, ebno_db / 20) * std::sqrt(((double)h->K) / ((double)h->N));
 }
 
@@ -379,6 +394,7 @@ int polar_decode_scl_llr_batch_dev_ev(polar_code_t *h, const double *d_llr, long
     p.frozen = h->d_frozen.p; p.info_rank = h->d_info_rank.p; p.crc_mask = h->d_crc_mask.p; p.tabs = h->d_tabs.p;
     p.ctl = h->d_ctl.p;
     p.pre = nullptr;
+    p.flags = nullptr; p.cw_list = nullptr; p.cw_count = nullptr;
     if (p.prefix_q) {
         if ((rc = h->d_pre.ensure((size_t)B * (size_t)(h->N - p.prefix_q + 1)))) return rc;
         p.pre = h->d_pre.p;
@@ -386,11 +402,43 @@ int polar_decode_scl_llr_batch_dev_ev(polar_code_t *h, const double *d_llr, long
     p.llr_scr = h->d_llr_scr.p; p.c_scr = h->d_c_scr.p; p.hist_scr = h->d_hist_scr.p;
     if ((rc = h->d_work.ensure(1))) return rc;
     p.work = h->d_work.p;
-    HIP_TRY(hipMemsetAsync(p.work, 0, sizeof(unsigned int), (hipStream_t)stream));
-    if (p.prefix_q) HIP_TRY(polar_launch_prefix(p, (hipStream_t)stream));
-    if (ev_start) HIP_TRY(hipEventRecord((hipEvent_t)ev_start, (hipStream_t)stream));
-    HIP_TRY(polar_launch_decode_llr(p, gs, lds_log, pipe, grid, (hipStream_t)stream));
-    if (ev_stop) HIP_TRY(hipEventRecord((hipEvent_t)ev_stop, (hipStream_t)stream));
+    hipStream_t st = (hipStream_t)stream;
+    // Node arithmetic: exp-domain kernel (one division per f-node instead of four transcendentals) for the
+    // list sizes where the f-node dominates; codewords it flags (decisions within 1e-10 of the |x| < 40
+    // test, degenerate inputs) are decoded again by the LLR-domain kernel in a fallback pass over a
+    // device-side work list: no host synchronisation, normally zero entries.
+    int mode = h->mode;
+    if (const char *e = getenv("POLAR_MODE")) mode = atoi(e);
+    const bool ed = (mode == 2) || (mode == 0 && gs >= 8);
+    if (ed && gs < 4) return fail(POLAR_E_ARG, "exp-domain mode needs a list size >= 3");
+    HIP_TRY(hipMemsetAsync(p.work, 0, sizeof(unsigned int), st));
+    if (!ed) {
+        if (p.prefix_q) HIP_TRY(polar_launch_prefix(p, false, st));
+        if (ev_start) HIP_TRY(hipEventRecord((hipEvent_t)ev_start, st));
+        HIP_TRY(polar_launch_decode_llr(p, gs, lds_log, pipe, grid, false, st));
+        if (ev_stop) HIP_TRY(hipEventRecord((hipEvent_t)ev_stop, st));
+        return POLAR_OK;
+    }
+    if ((rc = h->d_ech.ensure((size_t)B * h->N))) return rc;
+    if ((rc = h->d_flags.ensure((size_t)B))) return rc;
+    if ((rc = h->d_list.ensure((size_t)B))) return rc;
+    if ((rc = h->d_count.ensure(1))) return rc;
+    HIP_TRY(hipMemsetAsync(h->d_count.p, 0, sizeof(unsigned int), st));
+    HIP_TRY(polar_launch_ed_front(d_llr, h->d_ech.p, h->d_flags.p, h->d_tabs.p, h->N, B, st));
+    PolarDecodeParams pe = p;
+    pe.llr = h->d_ech.p; pe.flags = h->d_flags.p;
+    if (pe.prefix_q) HIP_TRY(polar_launch_prefix(pe, true, st));
+    if (ev_start) HIP_TRY(hipEventRecord((hipEvent_t)ev_start, st));
+    HIP_TRY(polar_launch_decode_llr(pe, gs, lds_log, pipe, grid, true, st));
+    if (ev_stop) HIP_TRY(hipEventRecord((hipEvent_t)ev_stop, st));
+    // fallback pass (LLR-domain kernel, no prefix kernel) over the flagged codewords
+    HIP_TRY(polar_launch_ed_collect(h->d_flags.p, B, h->d_list.p, h->d_count.p, st));
+    HIP_TRY(hipMemsetAsync(p.work, 0, sizeof(unsigned int), st));
+    PolarDecodeParams pf = p;
+    pf.prefix_q = 0; pf.prefix_len = 0; pf.pre = nullptr;
+    pf.cw_list = h->d_list.p; pf.cw_count = h->d_count.p;
+    const int fgrid = std::min(grid, 64 * wpb);
+    HIP_TRY(polar_launch_decode_llr(pf, gs, lds_log, pipe, fgrid, false, st));
     return POLAR_OK;
 }
 
@@ -469,6 +517,7 @@ int polar_decode_scl_p1_batch(polar_code_t *h, const double *p1, const double *p
     p.llr = h->d_in.p; p.p0 = h->d_in.p + (size_t)B * N; p.out = h->d_out.p; p.pm_out = nullptr;
     p.frozen = h->d_frozen.p; p.info_rank = h->d_info_rank.p; p.crc_mask = h->d_crc_mask.p; p.tabs = h->d_tabs.p;
     p.llr_scr = h->d_llr_scr.p; p.c_scr = h->d_c_scr.p; p.hist_scr = h->d_hist_scr.p;
+    p.flags = nullptr; p.cw_list = nullptr; p.cw_count = nullptr;
     HIP_TRY(polar_launch_decode_p1(p, gs, grid, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, h->d_out.p, (size_t)B * h->K, hipMemcpyDeviceToHost));

@@ -23,12 +23,18 @@ struct PolarDecodeParams {
     double *llr_scr;             // per-wave scratch: [grid][N - 2*SL][64]
     uint32_t *c_scr;             // per-wave scratch: [grid][2][N/32 - 2][64]
     uint32_t *hist_scr;          // per-wave scratch: [grid][W][64]
+    // exp-domain fast path + fallback pass
+    uint8_t *flags;              // [B] device (ED kernels): 1 = decode this codeword again with the LLR-domain kernel
+    const uint32_t *cw_list;     // work list of codeword indices (fallback pass), nullptr = 0..B-1
+    const unsigned int *cw_count;// device: number of entries of cw_list (read by the kernel), nullptr = B
 };
 
 size_t polar_decode_lds_bytes(int lds_log, int pipe);
 int polar_decode_waves_per_block(int pipe);
-hipError_t polar_launch_prefix(const PolarDecodeParams &p, hipStream_t st);
-hipError_t polar_launch_decode_llr(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, hipStream_t st);
+hipError_t polar_launch_prefix(const PolarDecodeParams &p, bool ed, hipStream_t st);
+hipError_t polar_launch_decode_llr(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, bool ed, hipStream_t st);
+hipError_t polar_launch_ed_front(const double *llr, double *ech, uint8_t *flags, const double *tabs, int N, long B, hipStream_t st);
+hipError_t polar_launch_ed_collect(const uint8_t *flags, long B, uint32_t *list, unsigned *count, hipStream_t st);
 
 hipError_t polar_launch_decode_p1(const PolarDecodeParams &p, int gs, int grid, hipStream_t st);
 

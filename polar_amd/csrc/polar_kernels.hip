@@ -198,12 +198,147 @@ __device__ __forceinline__ void softplus_pair(double a, bool skip, const Tabs &t
             spos = softplus_literal(a);
             return;
         }
-        hx = h_fn(a, tb);
+        // per-lane saturation: 1 + e^-a rounds to 1 for a >= 37, and an infinite (or > 1e78) leaf LLR must not
+        // reach the range reduction of exp_neg (inf * c - inf = NaN would poison the metric)
+        hx = (a >= 37.0) ? 0.0 : h_fn(__builtin_fmin(a, 37.0), tb);
     }
     sneg = hx;
     spos = (a > 709.782712893384) ? __builtin_inf() : a + hx;
 }
 
+
+// ================= exp-domain ("E-form") node arithmetic =======================================
+// The LLR-domain f-node needs four transcendentals (two exp + two log1p, ~70 instructions); in the
+// likelihood-ratio domain it is ONE division. A stored value v is
+//     |v| <= 1 :  E-form,  |v| = e^-|x|,  sign(v) = sign(x)          (x = the reference's LLR, |x| < T_E)
+//     |v| >  1 :  L-form,  v = x itself                               (|x| >= T_E = 690: e^-|x| would underflow)
+// so that a relative rounding error of 1.1e-16 in |v| is an ABSOLUTE error of 1.1e-16 in x: the same level
+// of accuracy as the table-driven LLR-domain f-node above (and as the reference's own 1 + e^x), for every
+// magnitude below 690.
+//     f exact (both |x| < 40, PolarCode.cpp:438-441):  E_y = (E_a + E_b) / (1 + E_a E_b),  sign = sa*sb
+//     f min-sum (:442-446):                            the input with the smaller |x|, sign = sa*sb
+//     g (:449-450), signs equal after (1-2u):          E_y = E_a E_b
+//                   signs opposite:                    E_y = min(E_a,E_b) / max(E_a,E_b), sign of the larger |x|
+//     g with an L-form input or an underflowing product (a few % of the wave-steps in the two lowest
+//     layers at 2 dB, none above): the reference's own addition in the LLR domain, with log / exp at the
+//     regime boundary only.
+// The path metric stays in the LLR domain: log(1+e^-|x|) = log1p(E), |x| = -log(E) at the leaves.
+// Decisions within ~1e-10 (relative) of the reference's |x| < 40 test are not taken here: the codeword is
+// flagged and decoded again by the LLR-domain kernel (guard mask, see scl_decode_llr_kernel).
+constexpr double ED_T = 690.0;                       // E-form iff |x| < ED_T
+constexpr double ED_EMIN = 2.3e-300;                 // < e^-690 = 2.26e-300 ... products below this leave the E-form
+constexpr double ED_C40_HI = 4.248354255291589e-18 * (1.0 + 1e-10);   // e^-40 (1 +- 1e-10)
+constexpr double ED_C40_LO = 4.248354255291589e-18 * (1.0 - 1e-10);
+#ifndef ED_NR
+#define ED_NR 2
+#endif
+// num / den for normal operands well inside the exponent range: v_rcp_f64 seed, Newton steps on the
+// reciprocal, one correction of the quotient (which squares the remaining error: <= 1 ulp)
+__device__ __forceinline__ double ed_div(double num, double den) {
+    double r = __builtin_amdgcn_rcp(den);
+    double e = __builtin_fma(-den, r, 1.0);
+    r = __builtin_fma(r, e, r);
+#if ED_NR >= 2
+    e = __builtin_fma(-den, r, 1.0);
+    r = __builtin_fma(r, e, r);
+#endif
+    const double q = num * r;
+    const double e2 = __builtin_fma(-den, q, num);
+    return __builtin_fma(e2, r, q);
+}
+__device__ __forceinline__ double ed_with_sign(double r, int signword) {     // r >= 0
+    return __hiloint2double(__double2hiint(r) | (signword & (int)0x80000000), __double2loint(r));
+}
+// f-node. `guard` collects (as a wave mask) the lanes whose |x| < 40 decision is too close to call.
+__device__ __forceinline__ double f_node_e(double a, double b, u64 &guard) {
+    const double fa = fabs(a), fb = fabs(b);
+    const double mx = __builtin_fmax(fa, fb), mn = __builtin_fmin(fa, fb);
+    const double q = ed_div(fa + fb, __builtin_fma(fa, fb, 1.0));
+    const u64 m_hi = __builtin_amdgcn_fcmp(mn, ED_C40_HI, 2);            // mn > e^-40 (1 + 1e-10): certainly |x| < 40
+    const u64 m_lo = __builtin_amdgcn_fcmp(mn, ED_C40_LO, 2);
+    const u64 m_e = __builtin_amdgcn_fcmp(mx, 1.0, 5);                   // both E-form
+    guard |= (m_hi ^ m_lo) & m_e;
+    // min-sum value: both E-form -> the larger E; one L-form -> the E-form one (mn); both L-form -> the smaller
+    const double ms = __builtin_amdgcn_inverse_ballot_w64(m_e) ? mx : mn;
+    const double r = __builtin_amdgcn_inverse_ballot_w64(m_hi & m_e) ? q : ms;
+    return ed_with_sign(r, __double2hiint(a) ^ __double2hiint(b));
+}
+// general natural logarithm of a positive normal double (tables of log_1p2)
+__device__ __forceinline__ double ed_log(double x, const Tabs &tb) {
+    const int hi = __double2hiint(x);
+    const double e = (double)((hi >> 20) - 1023);
+    const double m = __hiloint2double((hi & 0x000FFFFF) | 0x3FF00000, __double2loint(x));
+    // ln2 split: high part with 32 significant bits (e * hi is exact), low part the rest
+    return __builtin_fma(e, 6.93147180369123816490e-01, __builtin_fma(e, 1.90821492927058770002e-10, log_1p2(m, tb)));
+}
+// |x| of a stored value (E-form: -log E; L-form: itself)
+__device__ __forceinline__ double ed_abs_llr(double v, const Tabs &tb) {
+    const double m = fabs(v);
+    const double l = -ed_log(__builtin_fmin(__builtin_fmax(m, ED_EMIN), 1.0), tb);
+    return (m > 1.0) ? m : l;
+}
+// canonical stored form of an LLR x
+__device__ __forceinline__ double ed_from_llr(double x, const Tabs &tb) {
+    const double fx = fabs(x);
+    const double e = exp_neg(__builtin_fmin(fx, 700.0), tb);
+    return (fx >= ED_T) ? x : ed_with_sign(e, __double2hiint(x));
+}
+// g-node: (1-2u) a + b
+__device__ __forceinline__ double g_node_e(double a, double b, unsigned u, const Tabs &tb) {
+    const double fa = fabs(a), fb = fabs(b);
+    const int ha = __double2hiint(a) ^ (int)(u << 31), hb = __double2hiint(b);
+    const bool same = ((ha ^ hb) >= 0);
+    const double p = fa * fb;
+    const double lo = __builtin_fmin(fa, fb), hi = __builtin_fmax(fa, fb);
+    const double q = ed_div(lo, hi);                      // == 1.0 exactly when fa == fb (b - a = 0)
+    const double r = same ? p : q;
+    const int sg = same ? hb : ((fa < fb) ? ha : hb);     // opposite signs: the larger |x| (smaller E) decides
+    double res = ed_with_sign(r, sg);
+    const bool rare = (hi > 1.0) || (same && p < ED_EMIN);
+    if (__any(rare)) {
+        // reference arithmetic in the LLR domain for the lanes that need it
+        const double xa = ed_with_sign(ed_abs_llr(a, tb), ha), xb = ed_with_sign(ed_abs_llr(b, tb), hb);
+        const double y = xa + xb;
+        const double sl = ed_from_llr(y, tb);
+        if (rare) res = sl;
+    }
+    return res;
+}
+// channel LLR -> stored form, with the input guard (non-finite, or so small that the reference's f/g
+// results are its own rounding noise)
+__device__ __forceinline__ double ed_from_channel(double x, const Tabs &tb, bool &flag) {
+    const double fx = fabs(x);
+    flag = !(fx < __builtin_inf()) || fx < 1e-9;
+    return ed_from_llr(x, tb);
+}
+// leaf terms for the path metric. LLR-domain kernel: `leaf` is the LLR; E-domain: stored form.
+//   neg  = (llr < 0);  al = |llr|;  sneg = log(1+e^-|llr|);  spos = log(1+e^|llr|)
+template <bool ED>
+__device__ __forceinline__ void leaf_terms(double leaf, bool active, const Tabs &tb, bool &neg, double &al, double &sneg, double &spos) {
+    if (!ED) {
+        al = fabs(leaf);
+        neg = leaf < 0;
+        const bool skip = __all(!active || al >= 37.0);
+        sneg = 0.0; spos = 0.0;
+        if (active) softplus_pair(al, skip, tb, sneg, spos);
+    } else {
+        const double m = fabs(leaf);
+        const bool isl = m > 1.0;
+        neg = (__double2hiint(leaf) < 0) && m != 1.0;
+        al = m;
+        if (__any(active && !isl)) {
+            const double l = -ed_log(__builtin_fmin(__builtin_fmax(m, ED_EMIN), 1.0), tb);
+            if (!isl) al = l;
+        }
+        const double onep = 1.0 + m;                 // == 1 exactly from E <= 2^-53 on, as the reference's 1 + e^-|x|
+        sneg = 0.0;
+        if (__any(active && !isl && onep != 1.0)) {
+            const double h = log_1p2(__builtin_fmin(onep, 2.0), tb);
+            if (!isl) sneg = h;
+        }
+        spos = (al > 709.782712893384) ? __builtin_inf() : al + sneg;
+    }
+}
 }  // namespace
 
 // Layer storage helpers --------------------------------------------------------------------
@@ -224,8 +359,10 @@ __device__ __forceinline__ void softplus_pair(double a, bool skip, const Tabs &t
     const int lig = lane & (GS - 1);               \
     const int gbase = lane & ~(GS - 1);            \
     (void)lig; (void)gbase;
-template <int GS, int LDS_LOG, int PIPE>
+template <int GS, int LDS_LOG, int PIPE, bool ED>
 __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_llr_kernel(PolarDecodeParams p) {
+    // ED: exp-domain node arithmetic (see f_node_e); the channel values at p.llr are then in stored form
+    // (ed_front_kernel) and every codeword whose decisions are not safely reproduced is reported in p.flags
     // PIPE=1: one wave per block (8 waves/CU, register double-buffering); PIPE=0: four independent
     // waves per block sharing the transcendental tables (16 waves/CU with LDS_LOG = 3)
     constexpr int WPB = PIPE ? 1 : 4;
@@ -254,6 +391,14 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     for (int i = threadIdx.x; i < 322; i += WPB * 64) tabs[i] = p.tabs[i];
     if (WPB > 1) __syncthreads();
     const Tabs tb = {tabs, tabs + 64, tabs + 64 + 129};
+    u64 guard = 0;                                  // (ED) wave mask of lanes with an undecidable |x| < 40 test
+    auto FN = [&](double a, double b) -> double {
+        if constexpr (ED) return f_node_e(a, b, guard); else return f_node(a, b, tb);
+    };
+    auto GN = [&](double a, double b, unsigned u) -> double {
+        if constexpr (ED) return g_node_e(a, b, u, tb); else return g_node(a, b, u);
+    };
+    const long Bv = p.cw_count ? (long)*p.cw_count : p.B;      // (fallback pass: codewords come from p.cw_list)
 
     // per-wave global scratch
     const size_t big_elems = (N > 2 * SL) ? (size_t)(N - 2 * SL) : 0;
@@ -268,9 +413,19 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     // Work distribution: a wave's first group of codewords is its own index, every further one comes
     // from a device counter. Waves do not take equally long (per-wave time spreads by ~ +-15 %), and with
     // a static stride the launch ends when the unluckiest wave has finished ALL its groups.
-    for (long g0 = (long)wave_id * G; g0 < p.B;) {
-        const long cw = g0 + grp;
-        const bool valid = (cw < p.B);
+    for (long g0 = (long)wave_id * G; g0 < Bv;) {
+        const long cwi = g0 + grp;                 // position in the work list
+        const bool valid = (cwi < Bv);
+        const long cw = (p.cw_list && valid) ? (long)p.cw_list[cwi] : cwi;   // codeword (row of llr / out)
+        guard = 0;
+        auto cw_of_lane = [&](int ln) -> size_t {
+            const long i = g0 + ln / GS;
+            return p.cw_list ? (size_t)p.cw_list[i] : (size_t)i;
+        };
+        auto FN2 = [&](double a0_, double b0_, double a1_, double b1_, double &r0_, double &r1_) {
+            if constexpr (ED) { r0_ = f_node_e(a0_, b0_, guard); r1_ = f_node_e(a1_, b1_, guard); }
+            else f_node2(a0_, b0_, a1_, b1_, tb, r0_, r1_);
+        };
 
         // initializeDataStructures + assignInitialPath (PolarCode.cpp:195-272): the inactive
         // stack holds 0..L-1, the first pop (initial path) is L-1.
@@ -390,8 +545,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                         const bool in_is_ch = (lam == 1);
                         const bool in_pre = !in_is_ch && p.prefix_q > 0 && 2 * S >= p.prefix_q && phi < 2 * S;
                         // (active lanes are valid ones: codeword g0 + lane / GS)
-                        const double *in0 = in_is_ch ? p.llr + (size_t)(g0 + lane / GS) * N : nullptr;
-                        const double *pre_cw = in_pre ? p.pre + (size_t)(g0 + lane / GS) * (size_t)(N - p.prefix_q + 1) : nullptr;
+                        const double *in0 = in_is_ch ? p.llr + cw_of_lane(lane) * N : nullptr;
+                        const double *pre_cw = in_pre ? p.pre + cw_of_lane(lane) * (size_t)(N - p.prefix_q + 1) : nullptr;
                         const int pin = (in_is_ch || in_pre) ? 0 : pL.get(sh + 1);
                         const size_t istr = in_pre ? 1 : 64;      // prefix layers are contiguous per codeword
                         const double *gin = in_is_ch ? nullptr : (in_pre ? pre_cw + 1 + (size_t)(N - 4 * S)
@@ -435,15 +590,15 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                                     double x0, x1;
                                     if (odd) {
                                         const int bi = (S > 32) ? ((j + k) & 31) : (j + k);
-                                        x0 = g_node(a0[k], b0[k], (cb0 >> bi) & 1u);
-                                        x1 = g_node(a1[k], b1[k], (cb1 >> bi) & 1u);
+                                        x0 = GN(a0[k], b0[k], (cb0 >> bi) & 1u);
+                                        x1 = GN(a1[k], b1[k], (cb1 >> bi) & 1u);
                                     } else {
-                                        x0 = f_node(a0[k], b0[k], tb);
-                                        x1 = f_node(a1[k], b1[k], tb);
+                                        x0 = FN(a0[k], b0[k]);
+                                        x1 = FN(a1[k], b1[k]);
                                     }
                                     out0[(size_t)(j + k) * 64] = x0;
                                     out0[(size_t)(j + k + H) * 64] = x1;
-                                    out1[(size_t)(j + k) * 64] = f_node(x0, x1, tb);
+                                    out1[(size_t)(j + k) * 64] = FN(x0, x1);
                                 }
                             }
                         };
@@ -472,7 +627,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
 #pragma unroll
                             for (int j = 0; j < S_; ++j) { a[j] = li[(size_t)j * 64]; b[j] = li[(size_t)(j + S_) * 64]; }
 #pragma unroll
-                            for (int j = 0; j < S_; ++j) r[j] = odd ? g_node(a[j], b[j], (cb >> j) & 1u) : f_node(a[j], b[j], tb);
+                            for (int j = 0; j < S_; ++j) r[j] = odd ? GN(a[j], b[j], (cb >> j) & 1u) : FN(a[j], b[j]);
 #pragma unroll
                             for (int j = 0; j < S_; ++j) lo[(size_t)j * 64] = r[j];
                             leaf = r[S_ - 1];
@@ -496,8 +651,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     size_t istride;
                     const bool in_is_ch = (lam == 1);
                     const bool in_pre = !in_is_ch && p.prefix_q > 0 && 2 * S >= p.prefix_q && phi < 2 * S;
-                    const double *in0 = in_is_ch ? p.llr + (size_t)(g0 + lane / GS) * N : nullptr;
-                    const double *pre_cw = in_pre ? p.pre + (size_t)(g0 + lane / GS) * (size_t)(N - p.prefix_q + 1) : nullptr;
+                    const double *in0 = in_is_ch ? p.llr + cw_of_lane(lane) * N : nullptr;
+                    const double *pre_cw = in_pre ? p.pre + cw_of_lane(lane) * (size_t)(N - p.prefix_q + 1) : nullptr;
                     constexpr bool in_lds = false;          // (LDS inputs were handled above)
                     istride = 64;
                     if (in_pre) { inp = pre_cw + 1 + (size_t)(N - 4 * S); istride = 1; }
@@ -539,10 +694,10 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                             if (odd) {
                                 if (S > 32 && (j & 31) == 0) cbits = cwp[(size_t)(j >> 5) * 64];
 #pragma unroll
-                                for (int k = 0; k < U; ++k) r[k] = g_node(a[k], b[k], (cbits >> ((j + k) & 31)) & 1u);
+                                for (int k = 0; k < U; ++k) r[k] = GN(a[k], b[k], (cbits >> ((j + k) & 31)) & 1u);
                             } else {
 #pragma unroll
-                                for (int k = 0; k < U; ++k) r[k] = f_node(a[k], b[k], tb);
+                                for (int k = 0; k < U; ++k) r[k] = FN(a[k], b[k]);
                             }
 #pragma unroll
                             for (int k = 0; k < U; ++k) outp[(size_t)(j + k) * 64] = r[k];
@@ -574,10 +729,10 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                             if (odd) {
                                 if (S > 32 && (j & 31) == 0) cbits = cwp[(size_t)(j >> 5) * 64];
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) r[k] = g_node(a[k], b[k], (cbits >> ((j + k) & 31)) & 1u);
+                                for (int k = 0; k < 4; ++k) r[k] = GN(a[k], b[k], (cbits >> ((j + k) & 31)) & 1u);
                             } else {
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) r[k] = f_node(a[k], b[k], tb);
+                                for (int k = 0; k < 4; ++k) r[k] = FN(a[k], b[k]);
                             }
 #pragma unroll
                             for (int k = 0; k < 4; ++k) outp[(size_t)(j + k) * 64] = r[k];
@@ -593,7 +748,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                                 a = inp[(size_t)j * istride];
                                 b = inp[(size_t)(j + S) * istride];
                             }
-                            double r = odd ? g_node(a, b, (cbits >> j) & 1u) : f_node(a, b, tb);
+                            double r = odd ? GN(a, b, (cbits >> j) & 1u) : FN(a, b);
                             outp[(size_t)j * 64] = r;
                             leaf = r;
                         }
@@ -623,20 +778,16 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     double lf[4] = {0, 0, 0, 0};
                     if (active) {
                         double a0, a1;
-                        f_node2(v0, v2, v1, v3, tb, a0, a1);
-                        const double b0 = g_node(v0, v2, 0u), b1 = g_node(v1, v3, 0u);
-                        f_node2(a0, a1, b0, b1, tb, lf[0], lf[2]);
-                        lf[1] = g_node(a0, a1, 0u); lf[3] = g_node(b0, b1, 0u);
+                        FN2(v0, v2, v1, v3, a0, a1);
+                        const double b0 = GN(v0, v2, 0u), b1 = GN(v1, v3, 0u);
+                        FN2(a0, a1, b0, b1, lf[0], lf[2]);
+                        lf[1] = GN(a0, a1, 0u); lf[3] = GN(b0, b1, 0u);
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const double alz = fabs(lf[i]);
-                        const bool fz_skip = __all(!active || alz >= 37.0);
-                        if (active) {
-                            double sneg, spos;
-                            softplus_pair(alz, fz_skip, tb, sneg, spos);
-                            pm += (lf[i] < 0) ? spos : sneg;
-                        }
+                        bool ng; double alz, sneg, spos;
+                        leaf_terms<ED>(lf[i], active, tb, ng, alz, sneg, spos);
+                        if (active) pm += ng ? spos : sneg;
                     }
                 };
                 // (one instantiation per address space of the source: a maybe-LDS-maybe-global pointer would
@@ -648,8 +799,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 const double lo = yp[(size_t)j * 64], hi = yp[(size_t)(j + 4) * 64];
-                                a[j] = f_node(lo, hi, tb);
-                                b[j] = g_node(lo, hi, 0u);
+                                a[j] = FN(lo, hi);
+                                b[j] = GN(lo, hi, 0u);
                             }
                         }
                         block4(a[0], a[1], a[2], a[3]);
@@ -684,13 +835,9 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
             if (frozen) {
                 // continuePaths_FrozenBit: PolarCode.cpp:475-487
                 // PM += log(1+e^-llr): exactly 0 for llr >= 37, exactly |llr| (+0) for llr <= -37
-                const double alz = fabs(leaf);
-                const bool fz_skip = __all(!active || alz >= 37.0);
-                if (active) {
-                    double sneg, spos;
-                    softplus_pair(alz, fz_skip, tb, sneg, spos);
-                    pm += (leaf < 0) ? spos : sneg;
-                }
+                bool ng; double alz, sneg, spos;
+                leaf_terms<ED>(leaf, active, tb, ng, alz, sneg, spos);
+                if (active) pm += ng ? spos : sneg;
             } else {
                 // continuePaths_UnfrozenBit: PolarCode.cpp:489-607
                 const u64 actm = (__ballot(active) >> gbase) & gmask;
@@ -700,12 +847,11 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 // beats every "bad" fork of every path => the L survivors are the L good forks, nobody
                 // is killed or cloned.  good metric = PM + log(1+e^-|llr|) (the same sum the general
                 // path computes); bad metric = PM + log(1+e^|llr|) >= (PM + |llr|)(1 - 2^-40).
-                const double al = fabs(leaf);
+                bool lneg; double al;                      // llr < 0, |llr|
                 double gm = -__builtin_inf(), bl = __builtin_inf();
-                double sneg = 0.0, spos = 0.0;             // log(1+e^-|llr|), log(1+e^|llr|)
-                const bool sp_skip = __all(!active || al >= 37.0);
+                double sneg, spos;                         // log(1+e^-|llr|), log(1+e^|llr|)
+                leaf_terms<ED>(leaf, active, tb, lneg, al, sneg, spos);
                 if (active) {
-                    softplus_pair(al, sp_skip, tb, sneg, spos);
                     gm = pm + sneg;
                     bl = (pm + al) * 0.99999999999909050530;
                 }
@@ -734,7 +880,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 if (fast) {
                     PROF_CNT(9, 1)
                     if (active) {
-                        ubit = (leaf < 0) ? 1u : 0u;
+                        ubit = lneg ? 1u : 0u;
                         pm = gm;
                         hword |= ubit << (t & 31);
                     }
@@ -742,8 +888,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 } else {
                 double pf0 = __builtin_nan(""), pf1 = __builtin_nan("");
                 if (active) {
-                    pf0 = -(pm + ((leaf < 0) ? spos : sneg));     // -(PM + log(1+e^-llr)), PolarCode.cpp:505
-                    pf1 = -(pm + ((leaf < 0) ? sneg : spos));     // -(PM + log(1+e^llr)),  PolarCode.cpp:506
+                    pf0 = -(pm + (lneg ? spos : sneg));     // -(PM + log(1+e^-llr)), PolarCode.cpp:505
+                    pf1 = -(pm + (lneg ? sneg : spos));     // -(PM + log(1+e^llr)),  PolarCode.cpp:506
                 }
                 bool c0 = active, c1 = active;
                 const bool need = (2 * nact > L);          // otherwise every fork continues
@@ -754,7 +900,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     // whose lower bound is worse than every good fork (bl > gmax) can neither survive nor
                     // outrank a survivor, so only the L good forks and the few "competitive" bad forks
                     // are compared against: 32 LDS broadcasts + a short scalar loop instead of 64.
-                    const bool goodbit = (leaf < 0);                       // bit the leaf LLR favours
+                    const bool goodbit = lneg;                       // bit the leaf LLR favours
                     const double mg = goodbit ? -pf1 : -pf0;                // PM of my good / bad fork
                     const double mb = goodbit ? -pf0 : -pf1;
                     const bool cbad = active && full && !(bl > gmax);
@@ -984,6 +1130,10 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 p.out[(size_t)cw * K + b] = (uint8_t)((wd >> (r & 31)) & 1u);
             }
         }
+        if constexpr (ED) {
+            // codewords with an undecidable |x| < 40 test go to the LLR-domain kernel (host: fallback pass)
+            if (valid && lig == 0 && ((guard >> gbase) & gmask) != 0) p.flags[cw] = 1;
+        }
         wave_mem_fence();
         // next group
         if (p.work) {
@@ -1005,11 +1155,20 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
 // read; (2) the Q block values expanded in registers by a log2(Q)-stage butterfly into the Q leaf
 // LLRs; (3) the path metric accumulated over the first Pe leaves in order, same operations and order
 // as continuePaths_FrozenBit (PolarCode.cpp:475-487) -> pre[cw][0].
+template <bool ED>
 __global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p) {
     __shared__ double tabs[324];
+
     for (int i = threadIdx.x; i < 322; i += 256) tabs[i] = p.tabs[i];
     __syncthreads();
     const Tabs tb = {tabs, tabs + 64, tabs + 64 + 129};
+    u64 guard = 0;
+    auto FN = [&](double a, double b) -> double {
+        if constexpr (ED) return f_node_e(a, b, guard); else return f_node(a, b, tb);
+    };
+    auto GN0 = [&](double a, double b) -> double {
+        if constexpr (ED) return g_node_e(a, b, 0u, tb); else return g_node(a, b, 0u);
+    };
     const int lane = threadIdx.x & 63, lig = lane & 31, gbase = lane & 32;
     const int n = p.n, N = p.N, Q = p.prefix_q, Pe = p.prefix_len;
     const int R = Q >> 5;
@@ -1033,7 +1192,7 @@ __global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p) {
                     } else {
                         a = inp[j]; b = inp[j + S];
                     }
-                    const double r = f_node(a, b, tb);
+                    const double r = FN(a, b);
                     outp[j] = r;
                     if (S == Q) {
 #pragma unroll
@@ -1055,8 +1214,8 @@ __global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p) {
                         for (int r2 = 0; r2 < 8; ++r2) {
                             if (r2 == r + hr) {
                                 const double lo = x[r], hi = x[r2];
-                                x[r] = f_node(lo, hi, tb);
-                                x[r2] = g_node(lo, hi, 0u);
+                                x[r] = FN(lo, hi);
+                                x[r2] = GN0(lo, hi);
                             }
                         }
                     }
@@ -1067,7 +1226,7 @@ __global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p) {
                     if (r < R) {
                         const double mine = x[r];
                         const double other = shfl_d(mine, lane ^ h);
-                        x[r] = (lig & h) ? g_node(other, mine, 0u) : f_node(mine, other, tb);
+                        x[r] = (lig & h) ? GN0(other, mine) : FN(mine, other);
                     }
                 }
             }
@@ -1077,23 +1236,68 @@ __global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             if (r < R && r * 32 < Pe) {
-                const double al = fabs(x[r]);
-                double sneg, spos;
-                softplus_pair(al, false, tb, sneg, spos);
-                const double spv = (x[r] < 0) ? spos : sneg;
+                bool ng; double al, sneg, spos;
+                leaf_terms<ED>(x[r], true, tb, ng, al, sneg, spos);
+                const double spv = ng ? spos : sneg;
                 const int cnt = (Pe - r * 32 < 32) ? (Pe - r * 32) : 32;
                 for (int c = 0; c < cnt; ++c) acc += shfl_d(spv, gbase + c);
             }
         }
         if (valid && lig == 0) pre[0] = acc;
+        if constexpr (ED) {
+            if (valid && lig == 0 && ((guard >> gbase) & 0xFFFFFFFFull) != 0) p.flags[cw] = 1;
+            guard = 0;
+        }
         wave_mem_fence();
     }
 }
 
-hipError_t polar_launch_prefix(const PolarDecodeParams &p, hipStream_t st) {
+hipError_t polar_launch_prefix(const PolarDecodeParams &p, bool ed, hipStream_t st) {
     long blocks = (p.B + 7) / 8;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(prefix_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    if (ed) hipLaunchKernelGGL(prefix_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(prefix_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// ed_front_kernel — channel LLRs -> stored form of the exp-domain kernel (p.llr -> p.ech), plus the
+// input guard: flags[cw] = 1 when the codeword holds a non-finite LLR or one below 1e-9 (the
+// reference's f-node results are then its own rounding noise), else 0.
+__global__ __launch_bounds__(256) void ed_front_kernel(const double *llr, double *ech, uint8_t *flags, const double *tabs_g, int N, long B) {
+    __shared__ double tabs[324];
+    for (int i = threadIdx.x; i < 322; i += 256) tabs[i] = tabs_g[i];
+    __syncthreads();
+    const Tabs tb = {tabs, tabs + 64, tabs + 64 + 129};
+    const int lane = threadIdx.x & 63;
+    for (long cw = (long)blockIdx.x * 4 + (threadIdx.x >> 6); cw < B; cw += (long)gridDim.x * 4) {
+        const double *src = llr + (size_t)cw * N;
+        double *dst = ech + (size_t)cw * N;
+        bool any = false;
+        for (int i = lane; i < N; i += 64) {
+            bool f;
+            dst[i] = ed_from_channel(src[i], tb, f);
+            any |= f;
+        }
+        const bool bad = __any(any);
+        if (lane == 0) flags[cw] = bad ? 1 : 0;
+    }
+}
+hipError_t polar_launch_ed_front(const double *llr, double *ech, uint8_t *flags, const double *tabs, int N, long B, hipStream_t st) {
+    long blocks = (B + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(ed_front_kernel, dim3((unsigned)blocks), dim3(256), 0, st, llr, ech, flags, tabs, N, B);
+    return hipGetLastError();
+}
+// flagged codewords -> work list of the fallback pass (order irrelevant: every codeword is independent)
+__global__ __launch_bounds__(256) void ed_collect_kernel(const uint8_t *flags, long B, uint32_t *list, unsigned *count) {
+    for (long cw = (long)blockIdx.x * 256 + threadIdx.x; cw < B; cw += (long)gridDim.x * 256)
+        if (flags[cw]) list[atomicAdd(count, 1u)] = (uint32_t)cw;
+}
+hipError_t polar_launch_ed_collect(const uint8_t *flags, long B, uint32_t *list, unsigned *count, hipStream_t st) {
+    long blocks = (B + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(ed_collect_kernel, dim3((unsigned)blocks), dim3(256), 0, st, flags, B, list, count);
     return hipGetLastError();
 }
 
@@ -1103,12 +1307,12 @@ size_t polar_decode_lds_bytes(int lds_log, int pipe) {
     return 324 * 8 + (size_t)polar_decode_waves_per_block(pipe) * ((size_t)((2u << lds_log) - 1) * 64 * 8 + 128 * 8 + 128);
 }
 
-template <int GS>
+template <int GS, bool ED>
 static hipError_t launch_gs(const PolarDecodeParams &p, int lds_log, int pipe, int grid, hipStream_t st) {
     // `grid` counts WAVES; blocks = grid / waves-per-block (the host rounds grid to a multiple)
     size_t lds = polar_decode_lds_bytes(lds_log, pipe);
     const int wpb = polar_decode_waves_per_block(pipe);
-#define POLAR_LAUNCH(LL, PP) hipLaunchKernelGGL((scl_decode_llr_kernel<GS, LL, PP>), dim3(grid / wpb), dim3(64 * wpb), lds, st, p)
+#define POLAR_LAUNCH(LL, PP) hipLaunchKernelGGL((scl_decode_llr_kernel<GS, LL, PP, ED>), dim3(grid / wpb), dim3(64 * wpb), lds, st, p)
     switch (lds_log * 2 + (pipe ? 1 : 0)) {
         case 4: POLAR_LAUNCH(2, 0); break;
         case 6: POLAR_LAUNCH(3, 0); break;
@@ -1123,15 +1327,29 @@ static hipError_t launch_gs(const PolarDecodeParams &p, int lds_log, int pipe, i
     return hipGetLastError();
 }
 
-hipError_t polar_launch_decode_llr(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, hipStream_t st) {
+hipError_t polar_launch_decode_llr(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, bool ed, hipStream_t st) {
+    if (ed) {
+        switch (gs) {
+#ifndef POLAR_DEV_GS32
+            case 4: return launch_gs<4, true>(p, lds_log, pipe, grid, st);
+            case 8: return launch_gs<8, true>(p, lds_log, pipe, grid, st);
+            case 16: return launch_gs<16, true>(p, lds_log, pipe, grid, st);
+            case 64: return launch_gs<64, true>(p, lds_log, pipe, grid, st);
+#endif
+            case 32: return launch_gs<32, true>(p, lds_log, pipe, grid, st);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (gs) {
-        case 1: return launch_gs<1>(p, lds_log, pipe, grid, st);
-        case 2: return launch_gs<2>(p, lds_log, pipe, grid, st);
-        case 4: return launch_gs<4>(p, lds_log, pipe, grid, st);
-        case 8: return launch_gs<8>(p, lds_log, pipe, grid, st);
-        case 16: return launch_gs<16>(p, lds_log, pipe, grid, st);
-        case 32: return launch_gs<32>(p, lds_log, pipe, grid, st);
-        case 64: return launch_gs<64>(p, lds_log, pipe, grid, st);
+#ifndef POLAR_DEV_GS32
+        case 1: return launch_gs<1, false>(p, lds_log, pipe, grid, st);
+        case 2: return launch_gs<2, false>(p, lds_log, pipe, grid, st);
+        case 4: return launch_gs<4, false>(p, lds_log, pipe, grid, st);
+        case 8: return launch_gs<8, false>(p, lds_log, pipe, grid, st);
+        case 16: return launch_gs<16, false>(p, lds_log, pipe, grid, st);
+        case 64: return launch_gs<64, false>(p, lds_log, pipe, grid, st);
+#endif
+        case 32: return launch_gs<32, false>(p, lds_log, pipe, grid, st);
         default: return hipErrorInvalidValue;
     }
 }
