@@ -17,7 +17,9 @@ CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(ROOT, "include")
 LIB = os.path.join(HERE, "libpolar_amd.so")
 BUILD = os.path.join(HERE, "_build")
-SOURCES = ["polar_kernels.hip", "polar_kernels_p1.hip", "polar_channel.hip", "polar_construct.hip", "polar_host.cpp"]
+# (source, extra -D, object tag): polar_kernels.hip is compiled twice — LLR-domain and exp-domain kernel families
+SOURCES = [("polar_kernels.hip", ["POLAR_ED_TU=0"], ""), ("polar_kernels.hip", ["POLAR_ED_TU=1"], ".ed"),
+           ("polar_kernels_p1.hip", [], ""), ("polar_channel.hip", [], ""), ("polar_construct.hip", [], ""), ("polar_host.cpp", [], "")]
 ARCH = "gfx950"
 
 
@@ -56,21 +58,26 @@ def build(force=False, verbose=False, profile=False):
     headers = [os.path.join(INC, f) for f in os.listdir(INC)] + \
               [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     objs = []
-    for s in SOURCES:
+    jobs = []
+    for s, defs, otag in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(BUILD, s + tag + ".o")
+        obj = os.path.join(BUILD, s + otag + tag + ".o")
         objs.append(obj)
         if force or _newer(obj, [src] + headers + [os.path.abspath(__file__)]):
             cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                    "-Wall", "-Wno-unused-function", "-x", "hip", "-I", INC, "-I", CSRC, "-c", src, "-o", obj]
             if profile:
                 cmd.insert(1, "-DPOLAR_PROFILE")
-            for d in os.environ.get("POLAR_DEFS", "").split():
+            for d in defs + os.environ.get("POLAR_DEFS", "").split():
                 cmd.insert(1, "-D" + d)
             cmd[1:1] = os.environ.get("POLAR_HIPCC_FLAGS", "").split()    # A/B experiments with compiler options
             if verbose:
                 print(" ".join(cmd))
-            subprocess.check_call(cmd)
+            jobs.append(cmd)
+    if jobs:   # the translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(subprocess.check_call, jobs))
     if force or _newer(lib_out, objs):
         tl = _torch_lib()
         cmd = [_hipcc(), "-shared", "-fPIC", "-o", lib_out] + objs

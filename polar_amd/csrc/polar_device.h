@@ -75,10 +75,32 @@ __device__ __forceinline__ unsigned group_reduce_u32(unsigned v) {
     if (GS >= 64) v = op(v, dpp_u32<0x143, 0xC>(v));     // row_bcast31: rows 2, 3 <- lane 31
     return v;
 }
+// max of `a` and min of `b` over each group at once, as DPP-FUSED VOP2 instructions (the compiler expands the
+// update_dpp builtin above into mov + mov_dpp + max: three instructions per stage). The two chains are
+// interleaved so that each covers one of the other's two DPP wait states (VALU write -> DPP read); same result
+// placement as group_reduce_u32 (group_result_rows).
+template <int GS>
+__device__ __forceinline__ void group_max_min_u32(unsigned &a, unsigned &b) {
+#define POLAR_DPP_STAGE(CTRL)                                           \
+    asm volatile("s_nop 0\n\t"                                          \
+                 "v_max_u32_dpp %0, %0, %0 " CTRL "\n\t"                 \
+                 "v_min_u32_dpp %1, %1, %1 " CTRL : "+v"(a), "+v"(b));
+    asm volatile("s_nop 0");
+    if (GS >= 2) POLAR_DPP_STAGE("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+    if (GS >= 4) POLAR_DPP_STAGE("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+    if (GS >= 8) POLAR_DPP_STAGE("row_half_mirror row_mask:0xf bank_mask:0xf")
+    if (GS >= 16) POLAR_DPP_STAGE("row_mirror row_mask:0xf bank_mask:0xf")
+    if (GS >= 32) POLAR_DPP_STAGE("row_bcast:15 row_mask:0xa bank_mask:0xf")
+    if (GS >= 64) POLAR_DPP_STAGE("row_bcast:31 row_mask:0xc bank_mask:0xf")
+#undef POLAR_DPP_STAGE
+}
 template <int GS>
 __device__ __forceinline__ constexpr u64 group_result_rows() {
     return GS <= 16 ? ~0ull : (GS == 32 ? 0xFFFF0000FFFF0000ull : 0xFFFF000000000000ull);
 }
+// wave votes as ONE scalar compare of the ballot mask (HIP's __any/__all materialise a 0/1 VGPR first)
+__device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; }
+__device__ __forceinline__ bool wave_all(bool c) { return __builtin_amdgcn_ballot_w64(!c) == 0; }   // over the active lanes
 __device__ __forceinline__ void wave_mem_fence() {
     // lanes of one wave exchange data through LDS/global: keep the compiler from caching or
     // reordering across this point (hardware executes a wave's memory ops in order)

@@ -32,6 +32,10 @@ struct PolarDecodeParams {
 size_t polar_decode_lds_bytes(int lds_log, int pipe);
 int polar_decode_waves_per_block(int pipe);
 hipError_t polar_launch_prefix(const PolarDecodeParams &p, bool ed, hipStream_t st);
+hipError_t polar_launch_prefix_ed0(const PolarDecodeParams &p, hipStream_t st);
+hipError_t polar_launch_prefix_ed1(const PolarDecodeParams &p, hipStream_t st);
+hipError_t polar_launch_decode_llr_ed0(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, hipStream_t st);
+hipError_t polar_launch_decode_llr_ed1(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, hipStream_t st);
 hipError_t polar_launch_decode_llr(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, bool ed, hipStream_t st);
 hipError_t polar_launch_ed_front(const double *llr, double *ech, uint8_t *flags, const double *tabs, int N, long B, hipStream_t st);
 hipError_t polar_launch_ed_collect(const uint8_t *flags, long B, uint32_t *list, unsigned *count, hipStream_t st);

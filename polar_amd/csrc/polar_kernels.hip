@@ -167,13 +167,13 @@ __device__ __forceinline__ void f_node2(double a0, double b0, double a1, double 
     r0 = (mn0 == 0.0) ? 0.0 : m0;
     r1 = (mn1 == 0.0) ? 0.0 : m1;
     const bool e0 = 40 > mx0, e1 = 40 > mx1;
-    if (__any(e0 || e1)) {
+    if (wave_any(e0 || e1)) {
         const double x0 = m0 + h_diff(fabs(a0 + b0), fabs(a0 - b0), tb);
         const double x1 = m1 + h_diff(fabs(a1 + b1), fabs(a1 - b1), tb);
         const bool t0 = e0 && mn0 < 9.5367431640625e-07, t1 = e1 && mn1 < 9.5367431640625e-07;
         if (e0) r0 = x0;
         if (e1) r1 = x1;
-        if (__any(t0 || t1)) {                    // noise regime (see f_node)
+        if (wave_any(t0 || t1)) {                    // noise regime (see f_node)
             if (t0) r0 = f_literal(a0, b0);
             if (t1) r1 = f_literal(a1, b1);
         }
@@ -230,7 +230,7 @@ constexpr double ED_EMIN = 2.3e-300;                 // < e^-690 = 2.26e-300 ...
 constexpr double ED_C40_HI = 4.248354255291589e-18 * (1.0 + 1e-10);   // e^-40 (1 +- 1e-10)
 constexpr double ED_C40_LO = 4.248354255291589e-18 * (1.0 - 1e-10);
 #ifndef ED_NR
-#define ED_NR 2
+#define ED_NR 1     // v_rcp_f64 is good to 2^-24: one Newton step (2^-48) and the quotient correction (error squared again)
 #endif
 // num / den for normal operands well inside the exponent range: v_rcp_f64 seed, Newton steps on the
 // reciprocal, one correction of the quotient (which squares the remaining error: <= 1 ulp)
@@ -256,11 +256,12 @@ __device__ __forceinline__ double f_node_e(double a, double b, u64 &guard) {
     const double q = ed_div(fa + fb, __builtin_fma(fa, fb, 1.0));
     const u64 m_hi = __builtin_amdgcn_fcmp(mn, ED_C40_HI, 2);            // mn > e^-40 (1 + 1e-10): certainly |x| < 40
     const u64 m_lo = __builtin_amdgcn_fcmp(mn, ED_C40_LO, 2);
-    const u64 m_e = __builtin_amdgcn_fcmp(mx, 1.0, 5);                   // both E-form
-    guard |= (m_hi ^ m_lo) & m_e;
-    // min-sum value: both E-form -> the larger E; one L-form -> the E-form one (mn); both L-form -> the smaller
-    const double ms = __builtin_amdgcn_inverse_ballot_w64(m_e) ? mx : mn;
-    const double r = __builtin_amdgcn_inverse_ballot_w64(m_hi & m_e) ? q : ms;
+    const u64 m_l = __builtin_amdgcn_fcmp(mx, 1.0, 2);                   // an L-form input (rare)
+    guard |= (m_hi ^ m_lo) & ~m_l;
+    // both E-form: exact value, or (min-sum, :442-446) the smaller |x| = the larger E
+    double r = __builtin_amdgcn_inverse_ballot_w64(m_hi) ? q : mx;
+    // one L-form -> the E-form input (mn); both L-form -> the smaller |x| (mn)
+    if (m_l) r = __builtin_amdgcn_inverse_ballot_w64(m_l) ? mn : r;
     return ed_with_sign(r, __double2hiint(a) ^ __double2hiint(b));
 }
 // general natural logarithm of a positive normal double (tables of log_1p2)
@@ -283,24 +284,24 @@ __device__ __forceinline__ double ed_from_llr(double x, const Tabs &tb) {
     const double e = exp_neg(__builtin_fmin(fx, 700.0), tb);
     return (fx >= ED_T) ? x : ed_with_sign(e, __double2hiint(x));
 }
-// g-node: (1-2u) a + b
-__device__ __forceinline__ double g_node_e(double a, double b, unsigned u, const Tabs &tb) {
-    const double fa = fabs(a), fb = fabs(b);
-    const int ha = __double2hiint(a) ^ (int)(u << 31), hb = __double2hiint(b);
-    const bool same = ((ha ^ hb) >= 0);
-    const double p = fa * fb;
-    const double lo = __builtin_fmin(fa, fb), hi = __builtin_fmax(fa, fb);
-    const double q = ed_div(lo, hi);                      // == 1.0 exactly when fa == fb (b - a = 0)
+// g-node: (1-2u) a + b; `usign` carries u in bit 31 (the other bits are ignored)
+__device__ __forceinline__ double g_node_e(double a, double b, unsigned usign, const Tabs &tb) {
+    const int ha = __double2hiint(a) ^ (int)usign, hb = __double2hiint(b);      // only the sign bits of ha/hb are used
+    const bool same = (int)(ha ^ hb) >= 0;
+    const double p = fabs(a) * fabs(b);
+    const double lo = __builtin_fmin(fabs(a), fabs(b)), hi = __builtin_fmax(fabs(a), fabs(b));
+    const double q = ed_div(lo, hi);                      // == 1.0 exactly when |a| == |b| (b - a = 0)
     const double r = same ? p : q;
-    const int sg = same ? hb : ((fa < fb) ? ha : hb);     // opposite signs: the larger |x| (smaller E) decides
+    int sg = (fabs(a) < fabs(b)) ? ha : hb;               // opposite signs: the larger |x| (smaller E) decides
+    sg = same ? hb : sg;
     double res = ed_with_sign(r, sg);
-    const bool rare = (hi > 1.0) || (same && p < ED_EMIN);
-    if (__any(rare)) {
+    const u64 m_rare = __builtin_amdgcn_fcmp(hi, 1.0, 2) | __builtin_amdgcn_ballot_w64(same && p < ED_EMIN);
+    if (m_rare) {
         // reference arithmetic in the LLR domain for the lanes that need it
         const double xa = ed_with_sign(ed_abs_llr(a, tb), ha), xb = ed_with_sign(ed_abs_llr(b, tb), hb);
         const double y = xa + xb;
         const double sl = ed_from_llr(y, tb);
-        if (rare) res = sl;
+        if (__builtin_amdgcn_inverse_ballot_w64(m_rare)) res = sl;
     }
     return res;
 }
@@ -318,7 +319,7 @@ __device__ __forceinline__ void leaf_terms(double leaf, bool active, const Tabs 
     if (!ED) {
         al = fabs(leaf);
         neg = leaf < 0;
-        const bool skip = __all(!active || al >= 37.0);
+        const bool skip = wave_all(!active || al >= 37.0);
         sneg = 0.0; spos = 0.0;
         if (active) softplus_pair(al, skip, tb, sneg, spos);
     } else {
@@ -326,13 +327,13 @@ __device__ __forceinline__ void leaf_terms(double leaf, bool active, const Tabs 
         const bool isl = m > 1.0;
         neg = (__double2hiint(leaf) < 0) && m != 1.0;
         al = m;
-        if (__any(active && !isl)) {
+        if (wave_any(active && !isl)) {
             const double l = -ed_log(__builtin_fmin(__builtin_fmax(m, ED_EMIN), 1.0), tb);
             if (!isl) al = l;
         }
         const double onep = 1.0 + m;                 // == 1 exactly from E <= 2^-53 on, as the reference's 1 + e^-|x|
         sneg = 0.0;
-        if (__any(active && !isl && onep != 1.0)) {
+        if (wave_any(active && !isl && onep != 1.0)) {
             const double h = log_1p2(__builtin_fmin(onep, 2.0), tb);
             if (!isl) sneg = h;
         }
@@ -395,8 +396,9 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     auto FN = [&](double a, double b) -> double {
         if constexpr (ED) return f_node_e(a, b, guard); else return f_node(a, b, tb);
     };
-    auto GN = [&](double a, double b, unsigned u) -> double {
-        if constexpr (ED) return g_node_e(a, b, u, tb); else return g_node(a, b, u);
+    // g-node of element with partial-sum bit `bi` of the word `cw_` (u = (cw_ >> bi) & 1)
+    auto GN = [&](double a, double b, uint32_t cw_, int bi) -> double {
+        if constexpr (ED) return g_node_e(a, b, cw_ << (31 - bi), tb); else return g_node(a, b, (cw_ >> bi) & 1u);
     };
     const long Bv = p.cw_count ? (long)*p.cw_count : p.B;      // (fallback pass: codewords come from p.cw_list)
 
@@ -505,12 +507,21 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                         const uint32_t *cr = g_cr + (size_t)(nwd - 2) * 64 + lane;
                         uint32_t *dst = (to_right ? g_cr : g_cl) + (size_t)(2 * nwd - 2) * 64 + lane;
                         if (active) {
-                            for (int w = 0; w < nwd; ++w) {
-                                uint32_t r = cr[(size_t)w * 64];
-                                uint32_t l = cl[(size_t)w * 64];
-                                dst[(size_t)w * 64] = l ^ r;
-                                dst[(size_t)(w + nwd) * 64] = r;
-                            }
+                            // all loads of a chunk first, then the stores: one memory round trip per chunk instead of
+                            // one per word (a load behind a store waits for the store's acknowledgement as well)
+                            auto chunk = [&](auto CH_) {
+                                constexpr int CH = decltype(CH_)::value;
+                                for (int w = 0; w < nwd; w += CH) {
+                                    uint32_t r[CH], l[CH];
+#pragma unroll
+                                    for (int i = 0; i < CH; ++i) { r[i] = cr[(size_t)(w + i) * 64]; l[i] = cl[(size_t)(w + i) * 64]; }
+#pragma unroll
+                                    for (int i = 0; i < CH; ++i) { dst[(size_t)(w + i) * 64] = l[i] ^ r[i]; dst[(size_t)(w + i + nwd) * 64] = r[i]; }
+                                }
+                            };
+                            if (nwd >= 8) chunk(std::integral_constant<int, 8>{});
+                            else if (nwd == 4) chunk(std::integral_constant<int, 4>{});
+                            else chunk(std::integral_constant<int, 2>{});
                             if (!to_right) pC.set(sh + 1, lig);
                         }
                     }
@@ -540,6 +551,11 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 // is HBM-resident (channel LLRs or a scratch layer).
                 if (!PIPE && S >= 8 && 2 * S > SL && lam + 1 <= lam_stop && ((phi >> (sh - 1)) & 1) == 0) {   // (lam+1 is an f-visit)
                     const int H = S / 2;
+#ifdef POLAR_NO_FUSED4
+                    const bool deep = false;
+#else
+                    const bool deep = (lam + 3 <= lam_stop) && (phi & (S - 1)) == 0;        // four layers at once (else two)
+#endif
                     if (active) {
                         LANE_CTX
                         const bool in_is_ch = (lam == 1);
@@ -590,8 +606,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                                     double x0, x1;
                                     if (odd) {
                                         const int bi = (S > 32) ? ((j + k) & 31) : (j + k);
-                                        x0 = GN(a0[k], b0[k], (cb0 >> bi) & 1u);
-                                        x1 = GN(a1[k], b1[k], (cb1 >> bi) & 1u);
+                                        x0 = GN(a0[k], b0[k], cb0, bi);
+                                        x1 = GN(a1[k], b1[k], cb1, bi);
                                     } else {
                                         x0 = FN(a0[k], b0[k]);
                                         x1 = FN(a1[k], b1[k]);
@@ -602,20 +618,85 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                                 }
                             }
                         };
-                        if (S <= SL) fused_body(gin, lds_llr + (size_t)(S - 1) * 64 + lane, lds_llr + (size_t)(H - 1) * 64 + lane);
-                        else if (H <= SL) fused_body(gin, g_llr + (size_t)(S - 2 * SL) * 64 + lane, lds_llr + (size_t)(H - 1) * 64 + lane);
-                        else fused_body(gin, g_llr + (size_t)(S - 2 * SL) * 64 + lane, g_llr + (size_t)(H - 2 * SL) * 64 + lane);
+                        // ---- four layers in one pass (lam .. lam+3, sizes S, S/2, S/4, S/8): element j of the lowest
+                        // one is a 3-stage f-tree over the eight elements j + m*S/8 of layer lam, so none of the three
+                        // intermediate layers is re-read from HBM by the f-visit below it (they are still written:
+                        // the later g-visits need them). 16 loads in flight per pass, as the two-layer body.
+                        auto fused4 = [&](const double *inp, double *o0, double *o1, double *o2, double *o3) {
+                            const int E = S >> 3;
+                            uint32_t cw8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                            if (odd && S <= 32) cw8[0] = (uint32_t)(clsmall >> S);
+                            double a[8], b[8], v[8];
+                            auto load8 = [&](int j) {
+                                if (in_is_ch) {
+#pragma unroll
+                                    for (int m = 0; m < 8; ++m) {
+                                        const unsigned i0 = __brev((unsigned)(j + m * E)) >> (32 - n);
+                                        a[m] = in0[i0]; b[m] = in0[i0 + 1];
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int m = 0; m < 8; ++m) {
+                                        a[m] = inp[(size_t)(j + m * E) * istr]; b[m] = inp[(size_t)(j + m * E + S) * istr];
+                                    }
+                                }
+                            };
+                            for (int j = 0; j < E; ++j) {
+                                load8(j);
+                                if (odd && S > 32 && (j & 31) == 0) {
+#pragma unroll
+                                    for (int m = 0; m < 8; ++m) cw8[m] = cwp[(size_t)((j + m * E) >> 5) * 64];
+                                }
+#pragma unroll
+                                for (int m = 0; m < 8; ++m) {
+                                    if (odd) v[m] = (S > 32) ? GN(a[m], b[m], cw8[m], (j + m * E) & 31) : GN(a[m], b[m], cw8[0], j + m * E);
+                                    else v[m] = FN(a[m], b[m]);
+                                }
+                                // (issuing the next pass's loads here, ahead of the 15 stores, was measured: -15 % — the
+                                // double-buffered inputs do not fit the 128-VGPR budget)
+#pragma unroll
+                                for (int m = 0; m < 8; ++m) o0[(size_t)(j + m * E) * 64] = v[m];
+#pragma unroll
+                                for (int m = 0; m < 4; ++m) { v[m] = FN(v[m], v[m + 4]); o1[(size_t)(j + m * E) * 64] = v[m]; }
+#pragma unroll
+                                for (int m = 0; m < 2; ++m) { v[m] = FN(v[m], v[m + 2]); o2[(size_t)(j + m * E) * 64] = v[m]; }
+                                v[0] = FN(v[0], v[1]);
+                                o3[(size_t)j * 64] = v[0];
+                                leaf = v[0];            // (the leaf value when S/8 == 1)
+                            }
+                        };
+#define POLAR_GROW(T) (g_llr + (size_t)((T) - 2 * SL) * 64 + lane)
+#define POLAR_LROW(T) (lds_llr + (size_t)((T) - 1) * 64 + lane)
+                        if (deep) {
+                            const int Q = S / 4, E8 = S / 8;
+                            if (E8 > SL) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_GROW(Q), POLAR_GROW(E8));
+                            else if (Q > SL) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_GROW(Q), POLAR_LROW(E8));
+                            else if (H > SL) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_LROW(Q), POLAR_LROW(E8));
+                            else if (S > SL) fused4(gin, POLAR_GROW(S), POLAR_LROW(H), POLAR_LROW(Q), POLAR_LROW(E8));
+                            else fused4(gin, POLAR_LROW(S), POLAR_LROW(H), POLAR_LROW(Q), POLAR_LROW(E8));
+                            pL.set(sh - 2, lig);
+                            pL.set(sh - 3, lig);
+                        }
+                        else if (S <= SL) fused_body(gin, POLAR_LROW(S), POLAR_LROW(H));
+                        else if (H <= SL) fused_body(gin, POLAR_GROW(S), POLAR_LROW(H));
+                        else fused_body(gin, POLAR_GROW(S), POLAR_GROW(H));
+#undef POLAR_GROW
+#undef POLAR_LROW
                         pL.set(sh, lig);
                         pL.set(sh - 1, lig);
                     }
                     wave_mem_fence();
                     PROF(odd ? 1 : 2)
-                    ++lam;          // layer lam+1 is done
+                    lam += deep ? 3 : 1;          // layers lam+1 (.. lam+3) are done
                     continue;
                 }
                 // ---- both layers in LDS (the bottom of the tree, visited at almost every leaf): plain ds_read /
                 // ds_write on provably-LDS pointers, all inputs of the visit loaded before the first f
                 if (lam > 1 && 2 * S <= SL) {
+                    // the f-visits of the layers below follow immediately (phi is a multiple of S): they are taken
+                    // from registers in the same pass — `below` more layers, down to the leaf or the rate-0 block
+                    // (not at the resume point of the all-frozen prefix, where phi is not a multiple of S)
+                    const int below = ((phi & (S - 1)) == 0) ? lam_stop - lam : 0;
                     if (active) {
                         LANE_CTX
                         const double *li = lds_llr + (size_t)(2 * S - 1) * 64 + gbase + pL.get(sh + 1);
@@ -627,20 +708,32 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
 #pragma unroll
                             for (int j = 0; j < S_; ++j) { a[j] = li[(size_t)j * 64]; b[j] = li[(size_t)(j + S_) * 64]; }
 #pragma unroll
-                            for (int j = 0; j < S_; ++j) r[j] = odd ? GN(a[j], b[j], (cb >> j) & 1u) : FN(a[j], b[j]);
+                            for (int j = 0; j < S_; ++j) r[j] = odd ? GN(a[j], b[j], cb, j) : FN(a[j], b[j]);
 #pragma unroll
                             for (int j = 0; j < S_; ++j) lo[(size_t)j * 64] = r[j];
-                            leaf = r[S_ - 1];
+                            // layer of size T = S_ >> d from the one above (registers), stored for its later g-visit
+                            auto down = [&](auto TT) {
+                                constexpr int T = decltype(TT)::value;
+                                double *lt = lds_llr + (size_t)(T - 1) * 64 + lane;
+#pragma unroll
+                                for (int j = 0; j < T; ++j) { r[j] = FN(r[j], r[j + T]); lt[(size_t)j * 64] = r[j]; }
+                            };
+                            if constexpr (S_ >= 2) { if (below >= 1) down(std::integral_constant<int, S_ / 2>{}); }
+                            if constexpr (S_ >= 4) { if (below >= 2) down(std::integral_constant<int, S_ / 4>{}); }
+                            if constexpr (S_ >= 8) { if (below >= 3) down(std::integral_constant<int, S_ / 8>{}); }
+                            if constexpr (S_ >= 16) { if (below >= 4) down(std::integral_constant<int, S_ / 16>{}); }
+                            leaf = r[0];            // (the leaf LLR when the chain reached the layer of size 1)
                         };
                         if (S == 1) small(std::integral_constant<int, 1>{});
                         else if (S == 2) small(std::integral_constant<int, 2>{});
                         else if (S == 4) small(std::integral_constant<int, 4>{});
                         else if (S == 8) small(std::integral_constant<int, 8>{});
                         else small(std::integral_constant<int, 16>{});      // (lds_log = 5)
-                        pL.set(sh, lig);
+                        for (int d = 0; d <= below; ++d) pL.set(sh - d, lig);
                     }
                     wave_mem_fence();
                     PROF(S >= 4 ? 3 : 4)
+                    lam += below;
                     continue;
                 }
                 if (active) {
@@ -694,7 +787,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                             if (odd) {
                                 if (S > 32 && (j & 31) == 0) cbits = cwp[(size_t)(j >> 5) * 64];
 #pragma unroll
-                                for (int k = 0; k < U; ++k) r[k] = GN(a[k], b[k], (cbits >> ((j + k) & 31)) & 1u);
+                                for (int k = 0; k < U; ++k) r[k] = GN(a[k], b[k], cbits, (j + k) & 31);
                             } else {
 #pragma unroll
                                 for (int k = 0; k < U; ++k) r[k] = FN(a[k], b[k]);
@@ -729,7 +822,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                             if (odd) {
                                 if (S > 32 && (j & 31) == 0) cbits = cwp[(size_t)(j >> 5) * 64];
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) r[k] = GN(a[k], b[k], (cbits >> ((j + k) & 31)) & 1u);
+                                for (int k = 0; k < 4; ++k) r[k] = GN(a[k], b[k], cbits, (j + k) & 31);
                             } else {
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) r[k] = FN(a[k], b[k]);
@@ -748,7 +841,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                                 a = inp[(size_t)j * istride];
                                 b = inp[(size_t)(j + S) * istride];
                             }
-                            double r = odd ? GN(a, b, (cbits >> j) & 1u) : FN(a, b);
+                            double r = odd ? GN(a, b, cbits, j) : FN(a, b);
                             outp[(size_t)j * 64] = r;
                             leaf = r;
                         }
@@ -779,9 +872,9 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     if (active) {
                         double a0, a1;
                         FN2(v0, v2, v1, v3, a0, a1);
-                        const double b0 = GN(v0, v2, 0u), b1 = GN(v1, v3, 0u);
+                        const double b0 = GN(v0, v2, 0u, 0), b1 = GN(v1, v3, 0u, 0);
                         FN2(a0, a1, b0, b1, lf[0], lf[2]);
-                        lf[1] = GN(a0, a1, 0u); lf[3] = GN(b0, b1, 0u);
+                        lf[1] = GN(a0, a1, 0u, 0); lf[3] = GN(b0, b1, 0u, 0);
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -800,7 +893,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                             for (int j = 0; j < 4; ++j) {
                                 const double lo = yp[(size_t)j * 64], hi = yp[(size_t)(j + 4) * 64];
                                 a[j] = FN(lo, hi);
-                                b[j] = GN(lo, hi, 0u);
+                                b[j] = GN(lo, hi, 0u, 0);
                             }
                         }
                         block4(a[0], a[1], a[2], a[3]);
@@ -850,6 +943,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 bool lneg; double al;                      // llr < 0, |llr|
                 double gm = -__builtin_inf(), bl = __builtin_inf();
                 double sneg, spos;                         // log(1+e^-|llr|), log(1+e^|llr|)
+                // (a logarithm-free lower bound of |llr| for this test — exponent and mantissa of E — was measured:
+                // -1.5 %, the bound is short by up to 0.06 and sends more steps down the ranking path)
                 leaf_terms<ED>(leaf, active, tb, lneg, al, sneg, spos);
                 if (active) {
                     gm = pm + sneg;
@@ -864,8 +959,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 {
                     unsigned gh = active ? (unsigned)__double2hiint(gm) : 0u;
                     unsigned bh = active ? (unsigned)__double2hiint(bl) : 0xFFFFFFFFu;
-                    gh = group_reduce_u32<GS, true>(gh);
-                    bh = group_reduce_u32<GS, false>(bh);
+                    group_max_min_u32<GS>(gh, bh);
                     const bool ok = (nact == 0) || (nact == L && gh < bh);
                     fast = ((__ballot(ok) | ~group_result_rows<GS>()) == ~0ull);
                 }
@@ -873,7 +967,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 if (!fast) {
                     gmax = group_reduce<GS, true>(gm, lane);
                     const double bmin = group_reduce<GS, false>(bl, lane);
-                    fast = __all((nact == 0) || (nact == L && gmax < bmin));
+                    fast = wave_all((nact == 0) || (nact == L && gmax < bmin));
                 }
                 PROF_CNT(8, 1)
                 PROF(16)
@@ -894,7 +988,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 bool c0 = active, c1 = active;
                 const bool need = (2 * nact > L);          // otherwise every fork continues
                 const bool full = (nact == L);
-                if (!__any(need && !full)) {
+                if (!wave_any(need && !full)) {
                     // List full (the usual case). Rank = number of better forks in the reference's order
                     // (metric desc = PM asc, fork index asc on ties, PolarCode.cpp:528-553). A bad fork
                     // whose lower bound is worse than every good fork (bl > gmax) can neither survive nor
@@ -993,7 +1087,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 const u64 km = (__ballot(kill) >> gbase) & gmask;
                 const u64 bm = (__ballot(both) >> gbase) & gmask;
                 srcof[lane] = (unsigned char)lig;
-                if (__all(!active || full)) {
+                if (wave_all(!active || full)) {
                     // list full before the step => #kills == #clones: the kills are pushed (ascending l) and
                     // popped right back (LIFO) by the clones in ascending l, i.e. the r-th cloner revives the
                     // r-th LARGEST killed index; stack pointer and the entries below are untouched. One LDS
@@ -1020,7 +1114,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 // was ranked (PolarCode.cpp:580-582, 593, 601)
                 double pm_new = c0 ? -pf0 : -pf1;
                 ubit = c0 ? 0u : 1u;
-                if (__any(is_clone)) {
+                if (wave_any(is_clone)) {
                     const int sl = gbase + src;
                     double pm1 = shfl_d(-pf1, sl);
                     u64 a0 = shfl_u64(pL.lo, sl), a1 = shfl_u64(pL.hi, sl);
@@ -1252,14 +1346,26 @@ __global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p) {
     }
 }
 
-hipError_t polar_launch_prefix(const PolarDecodeParams &p, bool ed, hipStream_t st) {
+// This file is compiled twice (polar_amd/build.py): POLAR_ED_TU = 0 instantiates the LLR-domain kernels and
+// the small helper kernels, POLAR_ED_TU = 1 the exp-domain kernels — two translation units that build in parallel.
+#ifndef POLAR_ED_TU
+#define POLAR_ED_TU 0
+#endif
+#if POLAR_ED_TU
+hipError_t polar_launch_prefix_ed1(const PolarDecodeParams &p, hipStream_t st) {
+#else
+hipError_t polar_launch_prefix_ed0(const PolarDecodeParams &p, hipStream_t st) {
+#endif
     long blocks = (p.B + 7) / 8;
     if (blocks > 8192) blocks = 8192;
-    if (ed) hipLaunchKernelGGL(prefix_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(prefix_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(prefix_kernel<POLAR_ED_TU != 0>, dim3((unsigned)blocks), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 
+#if !POLAR_ED_TU
+hipError_t polar_launch_prefix(const PolarDecodeParams &p, bool ed, hipStream_t st) {
+    return ed ? polar_launch_prefix_ed1(p, st) : polar_launch_prefix_ed0(p, st);
+}
 // ------------------------------------------------------------------------------------------
 // ed_front_kernel — channel LLRs -> stored form of the exp-domain kernel (p.llr -> p.ech), plus the
 // input guard: flags[cw] = 1 when the codeword holds a non-finite LLR or one below 1e-9 (the
@@ -1279,7 +1385,7 @@ __global__ __launch_bounds__(256) void ed_front_kernel(const double *llr, double
             dst[i] = ed_from_channel(src[i], tb, f);
             any |= f;
         }
-        const bool bad = __any(any);
+        const bool bad = wave_any(any);
         if (lane == 0) flags[cw] = bad ? 1 : 0;
     }
 }
@@ -1307,6 +1413,8 @@ size_t polar_decode_lds_bytes(int lds_log, int pipe) {
     return 324 * 8 + (size_t)polar_decode_waves_per_block(pipe) * ((size_t)((2u << lds_log) - 1) * 64 * 8 + 128 * 8 + 128);
 }
 
+#endif  // !POLAR_ED_TU
+
 template <int GS, bool ED>
 static hipError_t launch_gs(const PolarDecodeParams &p, int lds_log, int pipe, int grid, hipStream_t st) {
     // `grid` counts WAVES; blocks = grid / waves-per-block (the host rounds grid to a multiple)
@@ -1327,19 +1435,21 @@ static hipError_t launch_gs(const PolarDecodeParams &p, int lds_log, int pipe, i
     return hipGetLastError();
 }
 
-hipError_t polar_launch_decode_llr(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, bool ed, hipStream_t st) {
-    if (ed) {
-        switch (gs) {
+#if POLAR_ED_TU
+hipError_t polar_launch_decode_llr_ed1(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, hipStream_t st) {
+    switch (gs) {
 #ifndef POLAR_DEV_GS32
-            case 4: return launch_gs<4, true>(p, lds_log, pipe, grid, st);
-            case 8: return launch_gs<8, true>(p, lds_log, pipe, grid, st);
-            case 16: return launch_gs<16, true>(p, lds_log, pipe, grid, st);
-            case 64: return launch_gs<64, true>(p, lds_log, pipe, grid, st);
+        case 4: return launch_gs<4, true>(p, lds_log, pipe, grid, st);
+        case 8: return launch_gs<8, true>(p, lds_log, pipe, grid, st);
+        case 16: return launch_gs<16, true>(p, lds_log, pipe, grid, st);
+        case 64: return launch_gs<64, true>(p, lds_log, pipe, grid, st);
 #endif
-            case 32: return launch_gs<32, true>(p, lds_log, pipe, grid, st);
-            default: return hipErrorInvalidValue;
-        }
+        case 32: return launch_gs<32, true>(p, lds_log, pipe, grid, st);
+        default: return hipErrorInvalidValue;
     }
+}
+#else
+hipError_t polar_launch_decode_llr_ed0(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, hipStream_t st) {
     switch (gs) {
 #ifndef POLAR_DEV_GS32
         case 1: return launch_gs<1, false>(p, lds_log, pipe, grid, st);
@@ -1353,3 +1463,7 @@ hipError_t polar_launch_decode_llr(const PolarDecodeParams &p, int gs, int lds_l
         default: return hipErrorInvalidValue;
     }
 }
+hipError_t polar_launch_decode_llr(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, bool ed, hipStream_t st) {
+    return ed ? polar_launch_decode_llr_ed1(p, gs, lds_log, pipe, grid, st) : polar_launch_decode_llr_ed0(p, gs, lds_log, pipe, grid, st);
+}
+#endif

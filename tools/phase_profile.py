@@ -36,13 +36,15 @@ a = prof[:24].cpu().numpy().astype(float)
 names = ["loop ovh", "layer S>SL g (HBM)", "layer S>SL f (HBM)", "layer 4<=S<=SL (LDS)", "layer S<4", "leaf frozen / rate-0 block", "leaf unfrozen (rest: flush etc.)", "partial sums", "unf: DPP reductions+decision", "unf: competitive-bad loop", "unf: stack/srcof", "unf: clone shuffles+update", "-", "unf: setup+goods rank loop", "unf: wait for leaf (ballot)", "unf: softplus+bounds"]
 print(f"L={L} B={B} time {dt*1e3:.2f} ms -> {B/dt:.0f} cw/s")
 cyc = a[:8].sum() + a[16:24].sum()
+nwd = B / (64 // max(1, 1 << (L - 1).bit_length()))      # wave-decodes
+print(f"  cycles per wave-decode: {cyc/nwd:.0f}")
 for nm, v in zip(names[:8], a[:8]):
-    print(f"  {nm:34s} {100*v/cyc:5.1f}%")
+    print(f"  {nm:34s} {100*v/cyc:5.1f}%  {v/nwd:10.0f} cycles/wave-decode")
 sub = ["unf: leaf wait + softplus + DPP bounds", "unf: fast path commit", "unf: goods rank loop", "unf: competitive-bad loop",
        "unf: kill/clone LIFO (LDS)", "unf: clone shuffles + update", "-", "-"]
 for nm, v in zip(sub, a[16:24]):
     if v:
-        print(f"    {nm:40s} {100*v/cyc:5.1f}%")
+        print(f"    {nm:40s} {100*v/cyc:5.1f}%  {v/nwd:10.0f}")
 if a[8] > 0:
     print(f"  unfrozen steps (per wave) {a[8]:.0f}: fast path {100*a[9]/a[8]:.1f}%, full-list ranking {100*a[10]/a[8]:.1f}%")
     if a[10] > 0:
