@@ -15,9 +15,13 @@
  *     device pointers resident in HBM plus a hipStream_t passed as void*.
  *   - LLR sign convention as the reference: llr = ln(p0/p1), positive => bit 0
  *     (PolarCode.cpp:752). Bits are one uint8_t per bit (0/1), as the reference.
- *   - a handle is bound to the HIP device that was current at creation; calls on one
- *     handle must be serialised by the caller (the reference object is not re-entrant
- *     either: PolarCode.h:56-68).
+ *   - a handle is bound to the HIP device that was current at creation (or, when none was visible
+ *     then, at its first compute call); every entry point runs there and restores the caller's current
+ *     device. Calls on one handle must be serialised by the caller (the reference object is not
+ *     re-entrant either: PolarCode.h:56-68), and the asynchronous "_dev" calls of one handle must all be
+ *     issued on ONE stream (or be ordered by the caller): they share the handle's device scratch.
+ *     A "_dev" call may (re)allocate that scratch when the batch or list size grows, which synchronises
+ *     the device once.
  *   - the decoders run ONLY on the GPU: without a usable HIP device they fail with
  *     POLAR_E_DEVICE. There is no CPU fallback in this library.
  */
@@ -121,21 +125,40 @@ int polar_count_errors_dev(polar_code_t *h, const uint8_t *d_a, const uint8_t *d
  * Batched Monte-Carlo on the synthetic workload. Semantics of the reference kept per trial
  * (one noise vector shared by every (L, Eb/N0); ascending Eb/N0 with "decoded at a lower
  * Eb/N0 => counted, not simulated", :728-742); the early stop `num_err > max_err` (:725)
- * is evaluated between batches of `batch` trials (batch = 1 reproduces the reference's
- * per-run granularity; batch = 0 picks min(max_runs, 65536)).  Reference defaults:
- * max_runs = 1000, max_err = 100 (:661-662).
- * Sharding: this rank simulates trials t with t % world == rank (counter-based RNG makes
- * the union independent of `world`); err/run accumulators are returned so the caller can
- * all-reduce them (RCCL) between batches: see polar_mc_* below for the step-wise form. */
+ * is evaluated between rounds of `batch` trials (batch = 1 reproduces the reference's per-run granularity).
+ * batch = 0 (the default of the host mirrors) picks the rounds itself: max(256, 2 max_err) trials first, then every
+ * round as large as all rounds before it together (at most 65536) — a point overshoots the reference's stopping
+ * time by less than 2x, and long sweeps still reach full-size launches. Reference defaults: max_runs = 1000,
+ * max_err = 100 (:661-662); PolarM: 500 / 50 (PolarCode.m:788-789).
+ * A round runs stream-ordered on the device (alive lists compacted there, PolarCode.cpp:728-742); the host reads
+ * the 2 n_L n_e counters once per round. */
 int polar_get_bler_quick(polar_code_t *h, const double *ebno, int n_e, const uint8_t *L, int n_L,
                          long max_runs, long max_err, uint64_t seed, long batch,
                          double *bler_out /*[n_L*n_e]*/);
+/* PolarM's second output (PolarCode.m:781, 839, 848): ber[i] = (differing info bits of the block errors) / num_run,
+ * per run as the reference computes it (NOT divided by K). Layout [n_L][n_e] like bler. */
+int polar_get_bler_quick_ber(polar_code_t *h, const double *ebno, int n_e, const uint8_t *L, int n_L,
+                             long max_runs, long max_err, uint64_t seed, long batch,
+                             double *bler_out /*[n_L*n_e]*/, double *ber_out /*[n_L*n_e]*/);
+/* The same sweep sharded over `n_dev` GPUs of this node from ONE host process (the C++ / MATLAB hosts): device
+ * devices[d] (NULL = 0..n_dev-1) simulates the trials d, d + n_dev, ... of every round on its own stream, with its
+ * own copy of the code tables and scratch (owned by `h`); the round's counters are summed with one RCCL
+ * ncclAllReduce(uint64, sum) over xGMI (bound at run time; a host-side sum when RCCL cannot be loaded, or with
+ * POLAR_NO_RCCL set). Counter-based inputs make the result independent of n_dev. *used_rccl (optional) reports
+ * which path summed the counters. ber_out may be NULL. */
+int polar_get_bler_quick_multi(polar_code_t *h, const int *devices, int n_dev, const double *ebno, int n_e,
+                               const uint8_t *L, int n_L, long max_runs, long max_err, uint64_t seed, long batch,
+                               double *bler_out, double *ber_out, int *used_rccl);
 
 /* step-wise Monte-Carlo for multi-GPU drivers: simulate trials {t0 + i*stride : i < T} for
  * every enabled (L, Eb/N0) point and ADD to err/run (host uint64 [n_L*n_e]). */
 int polar_mc_batch(polar_code_t *h, uint64_t seed, uint64_t t0, long T, long stride,
                    const double *ebno, int n_e, const uint8_t *L, int n_L,
                    const uint8_t *enabled /*[n_L*n_e]*/, uint64_t *err, uint64_t *run);
+/* same, also accumulating the differing info bits of the block errors (PolarM's num_bit_err, PolarCode.m:840) */
+int polar_mc_batch_ber(polar_code_t *h, uint64_t seed, uint64_t t0, long T, long stride,
+                       const double *ebno, int n_e, const uint8_t *L, int n_L,
+                       const uint8_t *enabled /*[n_L*n_e]*/, uint64_t *err, uint64_t *bit_err, uint64_t *run);
 
 /* ---- ASK Gray + BICM front end (PolarM/Constellation.m:84-93, 123-144; sweep conventions of
  * PolarM/main_MC_CC_Comparison.m:88-96) for the 16-ASK configuration: `constellation` is

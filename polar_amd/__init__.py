@@ -348,17 +348,40 @@ class PolarCode:
                                          C.c_long(stride), _p(snr, _dp), C.c_int(len(snr)), _p(Ls, _u8p),
                                          C.c_int(len(Ls)), _p(enabled, _u8p), _p(err, _u64p), _p(run, _u64p)))
 
-    def get_bler_quick(self, ebno_vec, list_size_vec, max_runs=1000, max_err=100, seed=1, batch=None):
-        """PolarCode::get_bler_quick: returns bler[len(list_size_vec)][len(ebno_vec)]."""
+    def mc_batch_ber(self, seed, t0, T, stride, ebno_vec, list_size_vec, enabled, err, bit_err, run):
+        ebno = np.ascontiguousarray(ebno_vec, np.float64)
+        Ls = np.ascontiguousarray(list_size_vec, np.uint8)
+        enabled = np.ascontiguousarray(enabled, np.uint8)
+        assert err.dtype == np.uint64 and run.dtype == np.uint64 and bit_err.dtype == np.uint64
+        _check(lib().polar_mc_batch_ber(self._h, C.c_uint64(seed), C.c_uint64(t0), C.c_long(T), C.c_long(stride),
+                                        _p(ebno, _dp), C.c_int(len(ebno)), _p(Ls, _u8p), C.c_int(len(Ls)),
+                                        _p(enabled, _u8p), _p(err, _u64p), _p(bit_err, _u64p), _p(run, _u64p)))
+
+    def get_bler_quick(self, ebno_vec, list_size_vec, max_runs=1000, max_err=100, seed=1, batch=None,
+                       return_ber=False, devices=None):
+        """PolarCode::get_bler_quick: returns bler[len(list_size_vec)][len(ebno_vec)] (PolarCode.cpp:658-785);
+        with return_ber=True also PolarM's second output ber (PolarCode.m:781,848), same layout.
+        batch=None: the library picks the rounds (see polar_amd.h). devices=[...]: shard the trials over these GPUs
+        of the node from this one process (polar_get_bler_quick_multi, RCCL all-reduce of the counters)."""
         ebno = np.ascontiguousarray(ebno_vec, np.float64)
         Ls = np.ascontiguousarray(list_size_vec, np.uint8)
         out = np.zeros((len(Ls), len(ebno)), np.float64)
+        ber = np.zeros((len(Ls), len(ebno)), np.float64)
         if batch is None:
-            batch = 0          # library default: min(max_runs, 65536)
-        _check(lib().polar_get_bler_quick(self._h, _p(ebno, _dp), C.c_int(len(ebno)), _p(Ls, _u8p), C.c_int(len(Ls)),
-                                          C.c_long(max_runs), C.c_long(max_err), C.c_uint64(seed), C.c_long(batch),
-                                          _p(out, _dp)))
-        return out
+            batch = 0
+        if devices is not None:
+            devs = np.ascontiguousarray(devices, np.int32)
+            used = C.c_int(0)
+            _check(lib().polar_get_bler_quick_multi(self._h, devs.ctypes.data_as(C.POINTER(C.c_int)), C.c_int(len(devs)),
+                                                    _p(ebno, _dp), C.c_int(len(ebno)), _p(Ls, _u8p), C.c_int(len(Ls)),
+                                                    C.c_long(max_runs), C.c_long(max_err), C.c_uint64(seed), C.c_long(batch),
+                                                    _p(out, _dp), _p(ber, _dp), C.byref(used)))
+            self.last_used_rccl = bool(used.value)
+        else:
+            _check(lib().polar_get_bler_quick_ber(self._h, _p(ebno, _dp), C.c_int(len(ebno)), _p(Ls, _u8p), C.c_int(len(Ls)),
+                                                  C.c_long(max_runs), C.c_long(max_err), C.c_uint64(seed), C.c_long(batch),
+                                                  _p(out, _dp), _p(ber, _dp)))
+        return (out, ber) if return_ber else out
 
 
 # ---- Monte-Carlo code construction (PolarM/PolarCode.m:95-196) ---------------------------------

@@ -78,15 +78,28 @@ public:
     }
 
     // PolarCode.cpp:658: bler[list_index][ebno_index]; reference constants max_err=100, max_runs=1000
+    // PolarCode.h:32-34. `devices` (optional): shard the trials of every round over these GPUs of the node
+    // (polar_get_bler_quick_multi: one RCCL all-reduce of the counters per round); `ber` (optional): PolarM's
+    // second output (PolarCode.m:781, 848), same layout as the result.
     std::vector<std::vector<double>> get_bler_quick(std::vector<double> ebno_vec, std::vector<uint8_t> list_size,
                                                     long max_runs = 1000, long max_err = 100, uint64_t seed = 1,
-                                                    long batch = 0) {
-        std::vector<double> flat(ebno_vec.size() * list_size.size());
-        check(polar_get_bler_quick(_h, ebno_vec.data(), (int)ebno_vec.size(), list_size.data(), (int)list_size.size(),
-                                   max_runs, max_err, seed, batch, flat.data()));   // batch 0: library default
+                                                    long batch = 0, std::vector<int> devices = {},
+                                                    std::vector<std::vector<double>> *ber = nullptr) {
+        std::vector<double> flat(ebno_vec.size() * list_size.size()), fber(flat.size());
+        if (devices.empty())
+            check(polar_get_bler_quick_ber(_h, ebno_vec.data(), (int)ebno_vec.size(), list_size.data(), (int)list_size.size(),
+                                           max_runs, max_err, seed, batch, flat.data(), fber.data()));   // batch 0: library rounds
+        else
+            check(polar_get_bler_quick_multi(_h, devices.data(), (int)devices.size(), ebno_vec.data(), (int)ebno_vec.size(),
+                                             list_size.data(), (int)list_size.size(), max_runs, max_err, seed, batch,
+                                             flat.data(), fber.data(), nullptr));
         std::vector<std::vector<double>> bler(list_size.size(), std::vector<double>(ebno_vec.size()));
+        if (ber) ber->assign(list_size.size(), std::vector<double>(ebno_vec.size()));
         for (size_t l = 0; l < list_size.size(); ++l)
-            for (size_t e = 0; e < ebno_vec.size(); ++e) bler[l][e] = flat[l * ebno_vec.size() + e];
+            for (size_t e = 0; e < ebno_vec.size(); ++e) {
+                bler[l][e] = flat[l * ebno_vec.size() + e];
+                if (ber) (*ber)[l][e] = fber[l * ebno_vec.size() + e];
+            }
         return bler;
     }
     polar_code_t *handle() { return _h; }

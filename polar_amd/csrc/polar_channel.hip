@@ -47,7 +47,8 @@ __global__ __launch_bounds__(64) void encode_kernel(PolarEncodeParams p) {
     volatile uint8_t *u = sm;          // [N]
     uint8_t *inf = sm + p.N;           // [K]
     const int lane = threadIdx.x;
-    for (long b = blockIdx.x; b < p.B; b += gridDim.x) {
+    const long Bv = p.n_dev ? ((long)*p.n_dev < p.B ? (long)*p.n_dev : p.B) : p.B;
+    for (long b = blockIdx.x; b < Bv; b += gridDim.x) {
         for (int i = lane; i < p.K; i += 64) inf[i] = p.info[(size_t)b * p.K + i];
         wave_sync();
         encode_in_lds(u, inf, p, lane);
@@ -62,7 +63,8 @@ __global__ __launch_bounds__(64) void synth_kernel(PolarEncodeParams p) {
     volatile uint8_t *u = sm;
     uint8_t *inf = sm + p.N;
     const int lane = threadIdx.x;
-    for (long b = blockIdx.x; b < p.B; b += gridDim.x) {
+    const long Bv = p.n_dev ? ((long)*p.n_dev < p.B ? (long)*p.n_dev : p.B) : p.B;
+    for (long b = blockIdx.x; b < Bv; b += gridDim.x) {
         const uint64_t trial = p.sel ? p.sel[b] : (p.trial0 + (uint64_t)b * (uint64_t)p.stride);
         const uint64_t block = trial / (uint64_t)p.info_block_div;   // 100: info refreshed every 100 runs, PolarCode.cpp:703-707
         for (int i = lane; i < p.K; i += 64) {
@@ -125,6 +127,28 @@ __global__ __launch_bounds__(64) void count_errors_kernel(const uint8_t *a, cons
     }
 }
 
+// ---- Monte-Carlo round, device side (no host round trip between the (L, Eb/N0) points) ----
+__global__ __launch_bounds__(256) void mc_init_alive_kernel(uint64_t *alive, unsigned *n, uint64_t t0, long stride, long T) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < T; i += (long)gridDim.x * 256) alive[i] = t0 + (uint64_t)i * (uint64_t)stride;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n = (unsigned)T;
+}
+__global__ __launch_bounds__(64) void mc_count_compact_kernel(const uint8_t *dec, const uint8_t *sent, long B, int K,
+                                                               const uint64_t *alive_in, const unsigned *n_in, uint64_t *alive_out,
+                                                               unsigned *n_out, unsigned long long *ctr) {
+    const int lane = threadIdx.x;
+    if ((long)*n_in < B) B = (long)*n_in;
+    for (long c = blockIdx.x; c < B; c += gridDim.x) {
+        unsigned nd = 0;
+        for (int i = lane; i < K; i += 64) nd += (dec[(size_t)c * K + i] != sent[(size_t)c * K + i]) ? 1u : 0u;
+        for (int off = 32; off >= 1; off >>= 1) nd += __shfl_xor(nd, off, 64);
+        if (lane == 0 && nd) {
+            atomicAdd(ctr, 1ull);
+            atomicAdd(ctr + 1, (unsigned long long)nd);
+            alive_out[atomicAdd(n_out, 1u)] = alive_in[c];
+        }
+    }
+}
+
 // float LLRs at the boundary (SURVEY §8b "numeric types at the edge"): widened exactly to the
 // reference's double before the decoder sees them
 __global__ __launch_bounds__(256) void widen_kernel(const float *src, double *dst, size_t n) {
@@ -147,6 +171,17 @@ hipError_t polar_launch_encode(const PolarEncodeParams &p, hipStream_t st) {
 }
 hipError_t polar_launch_synth(const PolarEncodeParams &p, hipStream_t st) {
     hipLaunchKernelGGL(synth_kernel, dim3(grid_for(p.B)), dim3(64), (size_t)p.N + p.K, st, p);
+    return hipGetLastError();
+}
+hipError_t polar_launch_mc_init_alive(uint64_t *alive, unsigned *n, uint64_t t0, long stride, long T, hipStream_t st) {
+    const long blocks = (T + 255) / 256;
+    hipLaunchKernelGGL(mc_init_alive_kernel, dim3((unsigned)(blocks < 1024 ? (blocks ? blocks : 1) : 1024)), dim3(256), 0, st, alive, n, t0, stride, T);
+    return hipGetLastError();
+}
+hipError_t polar_launch_mc_count_compact(const uint8_t *decoded, const uint8_t *sent, long B, int K,
+                                         const uint64_t *alive_in, const unsigned *n_in, uint64_t *alive_out, unsigned *n_out,
+                                         unsigned long long *ctr, hipStream_t st) {
+    hipLaunchKernelGGL(mc_count_compact_kernel, dim3(grid_for(B)), dim3(64), 0, st, decoded, sent, B, K, alive_in, n_in, alive_out, n_out, ctr);
     return hipGetLastError();
 }
 hipError_t polar_launch_count_errors(const uint8_t *a, const uint8_t *b, long B, int K,

@@ -7,7 +7,11 @@
 // decode path here: without a HIP device every compute entry point fails with POLAR_E_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
+#include <memory>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -94,6 +98,12 @@ struct polar_code {
     DevBuf<uint32_t> d_list;
     DevBuf<unsigned int> d_count;
     int mode = 0;                    // 0 auto, 1 LLR-domain kernel only, 2 exp-domain kernel + fallback pass
+    // Monte-Carlo engine (device side): alive lists (double-buffered), their lengths, per-round counters
+    DevBuf<uint64_t> d_alive[2];
+    DevBuf<unsigned int> d_nalive;           // [2]
+    DevBuf<unsigned long long> d_mc_ctr;     // [n_L*n_e][2]: block errors, bit errors of the round
+    // per-device clones for polar_get_bler_quick_multi (owned by this handle)
+    std::vector<polar_code *> clones;
     // tuning
     int waves_per_cu = 0, lds_log = 0, pipe = -1;
     bool prefix_on = true;
@@ -162,7 +172,16 @@ int upload(DevBuf<T> &d, const std::vector<T> &v) {
     return POLAR_OK;
 }
 
-int ensure_device(polar_code *h) {
+// Every compute entry point runs on the handle's device (the one current at creation) and leaves the
+// caller's current device as it found it.
+struct DevGuard {
+    int prev = -1;
+    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int ensure_device(polar_code *h, DevGuard &dg) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && h->device >= 0 && cur != h->device) dg.prev = cur;
     if (h->dev_ready) {
         HIP_TRY(hipSetDevice(h->device));
         return POLAR_OK;
@@ -172,7 +191,8 @@ int ensure_device(polar_code *h) {
     if (e != hipSuccess || cnt <= 0)
         return fail(POLAR_E_DEVICE, "no HIP device available (%s); this library has no CPU decode path",
                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
-    HIP_TRY(hipGetDevice(&h->device));
+    if (h->device < 0) HIP_TRY(hipGetDevice(&h->device));     // (created before any device was visible)
+    HIP_TRY(hipSetDevice(h->device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, h->device));
     h->num_cu = prop.multiProcessorCount;
@@ -241,6 +261,7 @@ int polar_create(int n, int K, double eps, int crc, polar_code_t **out) {
         for (int j = 0; j < K; ++j) h->crcm[(size_t)b * K + j] = (uint8_t)(rand() % 2);
     int rc = derive_tables(h);
     if (rc) { delete h; return rc; }
+    (void)hipGetDevice(&h->device);          // bound to the current device (stays -1 when none is visible yet)
     *out = h;
     return POLAR_OK;
 }
@@ -261,18 +282,27 @@ int polar_create_explicit(int n, int K, int crc, const uint8_t *frozen, const ui
     if (crc) memcpy(h->crcm.data(), crc_matrix, (size_t)crc * K);
     int rc = derive_tables(h);
     if (rc) { delete h; return rc; }
+    (void)hipGetDevice(&h->device);
     *out = h;
     return POLAR_OK;
 }
 
 void polar_destroy(polar_code_t *h) {
     if (!h) return;
+    for (polar_code *c : h->clones) polar_destroy(c);
+    h->clones.clear();
+    DevGuard dg_;
+    {
+        int cur = -1;
+        if (h->dev_ready && hipGetDevice(&cur) == hipSuccess && cur != h->device) dg_.prev = cur;
+    }
     if (h->dev_ready) (void)hipSetDevice(h->device);
     h->d_frozen.release(); h->d_ctl.release(); h->d_crcm.release(); h->d_order.release(); h->d_info_rank.release();
     h->d_crc_mask.release(); h->d_tabs.release(); h->d_pre.release(); h->d_llr_scr.release(); h->d_c_scr.release(); h->d_hist_scr.release();
     h->d_in.release(); h->d_f32.release(); h->d_out.release(); h->d_bytes_a.release(); h->d_bytes_b.release();
     h->d_counter.release(); h->d_sel.release(); h->d_work.release();
     h->d_ech.release(); h->d_flags.release(); h->d_list.release(); h->d_count.release();
+    h->d_alive[0].release(); h->d_alive[1].release(); h->d_nalive.release(); h->d_mc_ctr.release();
     delete h;
 }
 
@@ -317,6 +347,8 @@ int polar_set_tuning(polar_code_t *h, int waves_per_cu, int lds_log) {
     if (!h) return fail(POLAR_E_ARG, "NULL handle");
     if (waves_per_cu < 0 || waves_per_cu > 32) return fail(POLAR_E_ARG, "waves_per_cu out of range");
     if (lds_log != 0 && (lds_log < 2 || lds_log > 5)) return fail(POLAR_E_ARG, "lds_log must be 0 or 2..5");
+    if (lds_log == 2 && waves_per_cu != 0 && waves_per_cu <= 8)
+        return fail(POLAR_E_ARG, "lds_log = 2 exists only for the 4-wave-block kernels (waves_per_cu > 8)");
     h->waves_per_cu = waves_per_cu;
     h->lds_log = lds_log;
     return POLAR_OK;
@@ -340,13 +372,23 @@ int polar_decode_scl_llr_batch_dev(polar_code_t *h, const double *d_llr, long B,
     return polar_decode_scl_llr_batch_dev_ev(h, d_llr, B, L, d_out, d_pm, stream, nullptr, nullptr);
 }
 
+static int decode_impl(polar_code_t *h, const double *d_llr, long B, const unsigned int *n_dev, int L, uint8_t *d_out,
+                       double *d_pm, void *stream, void *ev_start, void *ev_stop);
+
 int polar_decode_scl_llr_batch_dev_ev(polar_code_t *h, const double *d_llr, long B, int L, uint8_t *d_out,
                                       double *d_pm, void *stream, void *ev_start, void *ev_stop) {
+    return decode_impl(h, d_llr, B, nullptr, L, d_out, d_pm, stream, ev_start, ev_stop);
+}
+
+// B rows are allocated; when n_dev != nullptr only the first min(B, *n_dev) exist (count read on the device)
+static int decode_impl(polar_code_t *h, const double *d_llr, long B, const unsigned int *n_dev, int L, uint8_t *d_out,
+                       double *d_pm, void *stream, void *ev_start, void *ev_stop) {
     if (!h || !d_llr || !d_out) return fail(POLAR_E_ARG, "NULL argument");
     if (L < 1 || L > POLAR_MAX_LIST) return fail(POLAR_E_ARG, "list size %d out of range [1, %d]", L, POLAR_MAX_LIST);
     if (B < 0) return fail(POLAR_E_ARG, "negative batch");
     if (B == 0) return POLAR_OK;
-    int rc = ensure_device(h);
+    DevGuard dg_;
+    int rc = ensure_device(h, dg_);
     if (rc) return rc;
     const int gs = pow2ceil(L);
     const int G = 64 / gs;
@@ -394,7 +436,7 @@ int polar_decode_scl_llr_batch_dev_ev(polar_code_t *h, const double *d_llr, long
     p.frozen = h->d_frozen.p; p.info_rank = h->d_info_rank.p; p.crc_mask = h->d_crc_mask.p; p.tabs = h->d_tabs.p;
     p.ctl = h->d_ctl.p;
     p.pre = nullptr;
-    p.flags = nullptr; p.cw_list = nullptr; p.cw_count = nullptr;
+    p.flags = nullptr; p.cw_list = nullptr; p.cw_count = nullptr; p.n_dev = n_dev;
     if (p.prefix_q) {
         if ((rc = h->d_pre.ensure((size_t)B * (size_t)(h->N - p.prefix_q + 1)))) return rc;
         p.pre = h->d_pre.p;
@@ -424,7 +466,7 @@ int polar_decode_scl_llr_batch_dev_ev(polar_code_t *h, const double *d_llr, long
     if ((rc = h->d_list.ensure((size_t)B))) return rc;
     if ((rc = h->d_count.ensure(1))) return rc;
     HIP_TRY(hipMemsetAsync(h->d_count.p, 0, sizeof(unsigned int), st));
-    HIP_TRY(polar_launch_ed_front(d_llr, h->d_ech.p, h->d_flags.p, h->d_tabs.p, h->N, B, st));
+    HIP_TRY(polar_launch_ed_front(d_llr, h->d_ech.p, h->d_flags.p, h->d_tabs.p, h->N, B, n_dev, st));
     PolarDecodeParams pe = p;
     pe.llr = h->d_ech.p; pe.flags = h->d_flags.p;
     if (pe.prefix_q) HIP_TRY(polar_launch_prefix(pe, true, st));
@@ -432,11 +474,11 @@ int polar_decode_scl_llr_batch_dev_ev(polar_code_t *h, const double *d_llr, long
     HIP_TRY(polar_launch_decode_llr(pe, gs, lds_log, pipe, grid, true, st));
     if (ev_stop) HIP_TRY(hipEventRecord((hipEvent_t)ev_stop, st));
     // fallback pass (LLR-domain kernel, no prefix kernel) over the flagged codewords
-    HIP_TRY(polar_launch_ed_collect(h->d_flags.p, B, h->d_list.p, h->d_count.p, st));
+    HIP_TRY(polar_launch_ed_collect(h->d_flags.p, B, n_dev, h->d_list.p, h->d_count.p, st));
     HIP_TRY(hipMemsetAsync(p.work, 0, sizeof(unsigned int), st));
     PolarDecodeParams pf = p;
     pf.prefix_q = 0; pf.prefix_len = 0; pf.pre = nullptr;
-    pf.cw_list = h->d_list.p; pf.cw_count = h->d_count.p;
+    pf.cw_list = h->d_list.p; pf.cw_count = h->d_count.p; pf.n_dev = nullptr;
     const int fgrid = std::min(grid, 64 * wpb);
     HIP_TRY(polar_launch_decode_llr(pf, gs, lds_log, pipe, fgrid, false, st));
     return POLAR_OK;
@@ -446,7 +488,8 @@ int polar_decode_scl_llr_batch(polar_code_t *h, const double *llr, long B, int L
     if (!h || !llr || !out) return fail(POLAR_E_ARG, "NULL argument");
     if (B < 0) return fail(POLAR_E_ARG, "negative batch");
     if (B == 0) return POLAR_OK;
-    int rc = ensure_device(h);
+    DevGuard dg_;
+    int rc = ensure_device(h, dg_);
     if (rc) return rc;
     if ((rc = h->d_in.ensure((size_t)B * h->N))) return rc;
     if ((rc = h->d_out.ensure((size_t)B * h->K))) return rc;
@@ -469,7 +512,8 @@ int polar_decode_scl_llr_batch_dev_f32(polar_code_t *h, const float *d_llr, long
     if (L < 1 || L > POLAR_MAX_LIST) return fail(POLAR_E_ARG, "list size %d out of range [1, %d]", L, POLAR_MAX_LIST);
     if (B < 0) return fail(POLAR_E_ARG, "negative batch");
     if (B == 0) return POLAR_OK;
-    int rc = ensure_device(h);
+    DevGuard dg_;
+    int rc = ensure_device(h, dg_);
     if (rc) return rc;
     if ((rc = h->d_in.ensure((size_t)B * h->N))) return rc;
     HIP_TRY(polar_launch_widen(d_llr, h->d_in.p, (size_t)B * h->N, (hipStream_t)stream));
@@ -479,7 +523,8 @@ int polar_decode_scl_llr_batch_f32(polar_code_t *h, const float *llr, long B, in
     if (!h || !llr || !out) return fail(POLAR_E_ARG, "NULL argument");
     if (B < 0) return fail(POLAR_E_ARG, "negative batch");
     if (B == 0) return POLAR_OK;
-    int rc = ensure_device(h);
+    DevGuard dg_;
+    int rc = ensure_device(h, dg_);
     if (rc) return rc;
     if ((rc = h->d_f32.ensure((size_t)B * h->N))) return rc;
     if ((rc = h->d_out.ensure((size_t)B * h->K))) return rc;
@@ -497,7 +542,8 @@ int polar_decode_scl_p1_batch(polar_code_t *h, const double *p1, const double *p
     if (L < 1 || L > POLAR_MAX_LIST) return fail(POLAR_E_ARG, "list size %d out of range [1, %d]", L, POLAR_MAX_LIST);
     if (B < 0) return fail(POLAR_E_ARG, "negative batch");
     if (B == 0) return POLAR_OK;
-    int rc = ensure_device(h);
+    DevGuard dg_;
+    int rc = ensure_device(h, dg_);
     if (rc) return rc;
     const int N = h->N;
     const int gs = pow2ceil(L), G = 64 / gs;
@@ -517,7 +563,7 @@ int polar_decode_scl_p1_batch(polar_code_t *h, const double *p1, const double *p
     p.llr = h->d_in.p; p.p0 = h->d_in.p + (size_t)B * N; p.out = h->d_out.p; p.pm_out = nullptr;
     p.frozen = h->d_frozen.p; p.info_rank = h->d_info_rank.p; p.crc_mask = h->d_crc_mask.p; p.tabs = h->d_tabs.p;
     p.llr_scr = h->d_llr_scr.p; p.c_scr = h->d_c_scr.p; p.hist_scr = h->d_hist_scr.p;
-    p.flags = nullptr; p.cw_list = nullptr; p.cw_count = nullptr;
+    p.flags = nullptr; p.cw_list = nullptr; p.cw_count = nullptr; p.n_dev = nullptr;
     HIP_TRY(polar_launch_decode_p1(p, gs, grid, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, h->d_out.p, (size_t)B * h->K, hipMemcpyDeviceToHost));
@@ -532,7 +578,8 @@ int polar_decode_sc_p1_batch(polar_code_t *h, const double *p1, long B, double *
     if (!h || !p1 || !out) return fail(POLAR_E_ARG, "NULL argument");
     if (B < 0) return fail(POLAR_E_ARG, "negative batch");
     if (B == 0) return POLAR_OK;
-    int rc = ensure_device(h);
+    DevGuard dg_;
+    int rc = ensure_device(h, dg_);
     if (rc) return rc;
     const int N = h->N;
     int grid = (int)std::min<long>((B + 63) / 64, (long)h->num_cu * 4);
@@ -562,7 +609,8 @@ static void fill_enc(const polar_code *h, PolarEncodeParams &p) {
 int polar_encode_batch_dev(polar_code_t *h, const uint8_t *d_info, long B, uint8_t *d_coded, void *stream) {
     if (!h || !d_info || !d_coded) return fail(POLAR_E_ARG, "NULL argument");
     if (B <= 0) return B == 0 ? POLAR_OK : fail(POLAR_E_ARG, "negative batch");
-    int rc = ensure_device(h);
+    DevGuard dg_;
+    int rc = ensure_device(h, dg_);
     if (rc) return rc;
     PolarEncodeParams p;
     fill_enc(h, p);
@@ -574,7 +622,8 @@ int polar_encode_batch_dev(polar_code_t *h, const uint8_t *d_info, long B, uint8
 int polar_encode_batch(polar_code_t *h, const uint8_t *info, long B, uint8_t *coded) {
     if (!h || !info || !coded) return fail(POLAR_E_ARG, "NULL argument");
     if (B <= 0) return B == 0 ? POLAR_OK : fail(POLAR_E_ARG, "negative batch");
-    int rc = ensure_device(h);
+    DevGuard dg_;
+    int rc = ensure_device(h, dg_);
     if (rc) return rc;
     if ((rc = h->d_bytes_a.ensure((size_t)B * h->K))) return rc;
     if ((rc = h->d_bytes_b.ensure((size_t)B * h->N))) return rc;
@@ -590,7 +639,8 @@ int polar_synth_llr_dev(polar_code_t *h, uint64_t seed, uint64_t trial0, long B,
                         double *d_llr, uint8_t *d_info, void *stream) {
     if (!h || !d_llr) return fail(POLAR_E_ARG, "NULL argument");
     if (B <= 0) return B == 0 ? POLAR_OK : fail(POLAR_E_ARG, "negative batch");
-    int rc = ensure_device(h);
+    DevGuard dg_;
+    int rc = ensure_device(h, dg_);
     if (rc) return rc;
     PolarEncodeParams p;
     fill_enc(h, p);
@@ -603,7 +653,8 @@ int polar_count_errors_dev(polar_code_t *h, const uint8_t *d_a, const uint8_t *d
                            unsigned long long *d_err_count, void *stream) {
     if (!h || !d_a || !d_b || !d_err_count) return fail(POLAR_E_ARG, "NULL argument");
     if (B <= 0) return B == 0 ? POLAR_OK : fail(POLAR_E_ARG, "negative batch");
-    int rc = ensure_device(h);
+    DevGuard dg_;
+    int rc = ensure_device(h, dg_);
     if (rc) return rc;
     HIP_TRY(polar_launch_count_errors(d_a, d_b, B, h->K, d_err_count, nullptr, (hipStream_t)stream));
     return POLAR_OK;
@@ -624,63 +675,92 @@ static void fill_channel(const polar_code *h, PolarEncodeParams &p, int constell
     }
 }
 
+// One Monte-Carlo round of T trials {t0 + i*stride} for every enabled (L, Eb/N0) point, entirely stream-ordered on
+// the device: per list size the alive list starts with all T trials; per point: synth(alive) -> decode -> count
+// block/bit errors and append the failing trials to the next alive list (PolarCode.cpp:728-742: a trial decoded at a
+// lower Eb/N0 is counted as run, not simulated). No host round trip between the points; the counters of the round
+// ([P][2] block errors, bit errors) stay in h->d_mc_ctr until mc_round_collect().
+static int mc_round_launch(polar_code_t *h, int constellation, uint64_t seed, uint64_t t0, long T, long stride,
+                           const double *ebno, int n_e, const uint8_t *Ls, int n_L, const uint8_t *enabled, hipStream_t st) {
+    const int N = h->N, K = h->K, P = n_e * n_L;
+    int rc;
+    if ((rc = h->d_in.ensure((size_t)T * N))) return rc;
+    if ((rc = h->d_out.ensure((size_t)T * K))) return rc;
+    if ((rc = h->d_bytes_a.ensure((size_t)T * K))) return rc;      // sent info
+    if ((rc = h->d_alive[0].ensure((size_t)T))) return rc;
+    if ((rc = h->d_alive[1].ensure((size_t)T))) return rc;
+    if ((rc = h->d_nalive.ensure(2))) return rc;
+    if ((rc = h->d_mc_ctr.ensure((size_t)2 * P))) return rc;
+    HIP_TRY(hipMemsetAsync(h->d_mc_ctr.p, 0, (size_t)2 * P * sizeof(unsigned long long), st));
+    for (int li = 0; li < n_L; ++li) {
+        int cur = 0;
+        bool first = true;
+        for (int ie = 0; ie < n_e; ++ie) {
+            if (!enabled[li * n_e + ie]) continue;                     // :725
+            if (first) {
+                HIP_TRY(polar_launch_mc_init_alive(h->d_alive[0].p, h->d_nalive.p, t0, stride, T, st));
+                cur = 0; first = false;
+            }
+            const int nxt = cur ^ 1;
+            HIP_TRY(hipMemsetAsync(h->d_nalive.p + nxt, 0, sizeof(unsigned int), st));
+            PolarEncodeParams p;
+            fill_enc(h, p);
+            p.B = T; p.seed = seed; p.sel = h->d_alive[cur].p; p.n_dev = h->d_nalive.p + cur;
+            fill_channel(h, p, constellation, ebno[ie]);
+            p.llr = h->d_in.p; p.info_out = h->d_bytes_a.p;
+            HIP_TRY(polar_launch_synth(p, st));
+            if ((rc = decode_impl(h, h->d_in.p, T, h->d_nalive.p + cur, Ls[li], h->d_out.p, nullptr, st, nullptr, nullptr))) return rc;
+            HIP_TRY(polar_launch_mc_count_compact(h->d_out.p, h->d_bytes_a.p, T, K, h->d_alive[cur].p, h->d_nalive.p + cur,
+                                                  h->d_alive[nxt].p, h->d_nalive.p + nxt, h->d_mc_ctr.p + 2 * (size_t)(li * n_e + ie), st));
+            cur = nxt;
+        }
+    }
+    return POLAR_OK;
+}
+// the counters of the last round -> host accumulators (err, bit_err may be NULL); run += T for every enabled point (:728)
+static int mc_round_collect(polar_code_t *h, long T, int P, const uint8_t *enabled, uint64_t *err, uint64_t *bit_err, uint64_t *run, hipStream_t st) {
+    std::vector<unsigned long long> c((size_t)2 * P);
+    HIP_TRY(hipMemcpyAsync(c.data(), h->d_mc_ctr.p, c.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int i = 0; i < P; ++i) {
+        if (!enabled[i]) continue;
+        if (err) err[i] += (uint64_t)c[2 * i];
+        if (bit_err) bit_err[i] += (uint64_t)c[2 * i + 1];
+        if (run) run[i] += (uint64_t)T;
+    }
+    return POLAR_OK;
+}
+
 static int mc_batch_impl(polar_code_t *h, int constellation, uint64_t seed, uint64_t t0, long T, long stride,
                          const double *ebno, int n_e, const uint8_t *Ls, int n_L,
-                         const uint8_t *enabled, uint64_t *err, uint64_t *run) {
+                         const uint8_t *enabled, uint64_t *err, uint64_t *bit_err, uint64_t *run) {
     if (!h || !ebno || !Ls || !enabled || !err || !run) return fail(POLAR_E_ARG, "NULL argument");
     if (T <= 0 || stride <= 0 || n_e <= 0 || n_L <= 0) return fail(POLAR_E_ARG, "bad sizes");
     for (int i = 0; i < n_L; ++i)
         if (Ls[i] < 1 || Ls[i] > POLAR_MAX_LIST) return fail(POLAR_E_ARG, "list size %d out of range", (int)Ls[i]);
-    int rc = ensure_device(h);
+    DevGuard dg_;
+    int rc = ensure_device(h, dg_);
     if (rc) return rc;
-    const int N = h->N, K = h->K;
-    if ((rc = h->d_in.ensure((size_t)T * N))) return rc;
-    if ((rc = h->d_out.ensure((size_t)T * K))) return rc;
-    if ((rc = h->d_bytes_a.ensure((size_t)T * K))) return rc;      // sent info
-    if ((rc = h->d_bytes_b.ensure((size_t)T))) return rc;          // mismatch flags
-    if ((rc = h->d_sel.ensure((size_t)T))) return rc;
-    std::vector<uint64_t> alive, next;
-    std::vector<uint8_t> flags((size_t)T);
-    for (int li = 0; li < n_L; ++li) {
-        // trials still to be simulated for this list size: every trial until it is decoded
-        // correctly at some (lower) Eb/N0 — the reference's prev_decoded hack (:732-742)
-        alive.resize((size_t)T);
-        for (long i = 0; i < T; ++i) alive[i] = t0 + (uint64_t)i * (uint64_t)stride;
-        for (int ie = 0; ie < n_e; ++ie) {
-            if (!enabled[li * n_e + ie]) continue;                     // :725
-            run[li * n_e + ie] += (uint64_t)T;                         // :728 (counted even when skipped)
-            const long A = (long)alive.size();
-            if (A == 0) continue;
-            HIP_TRY(hipMemcpy(h->d_sel.p, alive.data(), (size_t)A * sizeof(uint64_t), hipMemcpyHostToDevice));
-            PolarEncodeParams p;
-            fill_enc(h, p);
-            p.B = A; p.seed = seed; p.sel = h->d_sel.p;
-            fill_channel(h, p, constellation, ebno[ie]);
-            p.llr = h->d_in.p; p.info_out = h->d_bytes_a.p;
-            HIP_TRY(polar_launch_synth(p, nullptr));
-            if ((rc = polar_decode_scl_llr_batch_dev(h, h->d_in.p, A, Ls[li], h->d_out.p, nullptr, nullptr))) return rc;
-            HIP_TRY(polar_launch_count_errors(h->d_out.p, h->d_bytes_a.p, A, K, nullptr, h->d_bytes_b.p, nullptr));
-            HIP_TRY(hipMemcpy(flags.data(), h->d_bytes_b.p, (size_t)A, hipMemcpyDeviceToHost));
-            next.clear();
-            for (long i = 0; i < A; ++i)
-                if (flags[i]) { err[li * n_e + ie]++; next.push_back(alive[i]); }   // :766-769
-            alive.swap(next);
-        }
-    }
-    return POLAR_OK;
+    if ((rc = mc_round_launch(h, constellation, seed, t0, T, stride, ebno, n_e, Ls, n_L, enabled, nullptr))) return rc;
+    return mc_round_collect(h, T, n_e * n_L, enabled, err, bit_err, run, nullptr);
 }
 
 int polar_mc_batch(polar_code_t *h, uint64_t seed, uint64_t t0, long T, long stride,
                    const double *ebno, int n_e, const uint8_t *Ls, int n_L,
                    const uint8_t *enabled, uint64_t *err, uint64_t *run) {
-    return mc_batch_impl(h, 0, seed, t0, T, stride, ebno, n_e, Ls, n_L, enabled, err, run);
+    return mc_batch_impl(h, 0, seed, t0, T, stride, ebno, n_e, Ls, n_L, enabled, err, nullptr, run);
+}
+int polar_mc_batch_ber(polar_code_t *h, uint64_t seed, uint64_t t0, long T, long stride,
+                       const double *ebno, int n_e, const uint8_t *Ls, int n_L,
+                       const uint8_t *enabled, uint64_t *err, uint64_t *bit_err, uint64_t *run) {
+    return mc_batch_impl(h, 0, seed, t0, T, stride, ebno, n_e, Ls, n_L, enabled, err, bit_err, run);
 }
 int polar_mc_batch_bicm(polar_code_t *h, int constellation, uint64_t seed, uint64_t t0, long T, long stride,
                         const double *snr_db, int n_s, const uint8_t *Ls, int n_L,
                         const uint8_t *enabled, uint64_t *err, uint64_t *run) {
     if (constellation < POLAR_CONST_ASK4_GRAY || constellation > POLAR_CONST_ASK16_GRAY)
         return fail(POLAR_E_ARG, "unknown constellation %d", constellation);
-    return mc_batch_impl(h, constellation, seed, t0, T, stride, snr_db, n_s, Ls, n_L, enabled, err, run);
+    return mc_batch_impl(h, constellation, seed, t0, T, stride, snr_db, n_s, Ls, n_L, enabled, err, nullptr, run);
 }
 int polar_synth_bicm_llr_dev(polar_code_t *h, int constellation, uint64_t seed, uint64_t trial0, long B, double snr_db,
                              double *d_llr, uint8_t *d_info, void *stream) {
@@ -688,7 +768,8 @@ int polar_synth_bicm_llr_dev(polar_code_t *h, int constellation, uint64_t seed, 
     if (constellation < POLAR_CONST_ASK4_GRAY || constellation > POLAR_CONST_ASK16_GRAY)
         return fail(POLAR_E_ARG, "unknown constellation %d", constellation);
     if (B <= 0) return B == 0 ? POLAR_OK : fail(POLAR_E_ARG, "negative batch");
-    int rc = ensure_device(h);
+    DevGuard dg_;
+    int rc = ensure_device(h, dg_);
     if (rc) return rc;
     PolarEncodeParams p;
     fill_enc(h, p);
@@ -746,24 +827,188 @@ int polar_mc_construction(int n, int constellation, double design_snr_db, uint64
     return POLAR_OK;
 }
 
-int polar_get_bler_quick(polar_code_t *h, const double *ebno, int n_e, const uint8_t *Ls, int n_L,
-                         long max_runs, long max_err, uint64_t seed, long batch, double *bler_out) {
+}  // extern "C" (first part)
+
+// ---- PolarCode::get_bler_quick on 1..n GPUs ---------------------------------------------------------------------
+namespace {
+
+// RCCL, bound at run time (the library has no link-time dependency on it): the copy that sits next to the HIP
+// runtime this process uses (PyTorch bundles both), else the ROCm one.
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool load() {
+        if (lib) return true;
+        std::vector<std::string> cand;
+        Dl_info info;
+        if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
+            std::string d(info.dli_fname);
+            size_t k = d.rfind('/');
+            if (k != std::string::npos) cand.push_back(d.substr(0, k + 1) + "librccl.so");
+        }
+        cand.push_back("librccl.so");
+        cand.push_back("/opt/rocm/lib/librccl.so");
+        for (const std::string &c : cand) {
+            lib = dlopen(c.c_str(), RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) return false;
+        CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
+        GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        return CommInitAll && CommDestroy && AllReduce;
+    }
+};
+Rccl g_rccl;
+constexpr int kNcclUint64 = 5, kNcclSum = 0;     // rccl.h: ncclUint64, ncclSum
+
+// the handle's tables on another device (owned by `h`, reused by later calls)
+polar_code *clone_on_device(polar_code *h, int dev) {
+    if (dev == h->device) return h;
+    for (polar_code *c : h->clones) if (c->device == dev) return c;
+    polar_code *c = new polar_code;
+    c->n = h->n; c->N = h->N; c->K = h->K; c->crc = h->crc; c->eps = h->eps;
+    c->frozen = h->frozen; c->order = h->order; c->bitrev = h->bitrev; c->crcm = h->crcm;
+    c->W = h->W; c->info_rank = h->info_rank; c->crc_mask = h->crc_mask; c->sched = h->sched; c->ctl = h->ctl;
+    c->device = dev;
+    c->waves_per_cu = h->waves_per_cu; c->lds_log = h->lds_log; c->prefix_on = h->prefix_on; c->mode = h->mode;
+    h->clones.push_back(c);
+    return c;
+}
+
+// round sizes: `batch` fixed, or (batch == 0) geometric — the first round is max(256, 2 max_err) trials, every later
+// one as many as all rounds before it together (at most 65536): the early stop `num_err > max_err` (:725) keeps its
+// meaning (a point overshoots its stopping time by less than 2x) and long sweeps still reach full-size launches
+long next_round(long batch, long max_err, long done, long max_runs) {
+    long T = batch > 0 ? batch : (done == 0 ? std::max<long>(256, 2 * max_err) : std::min<long>(done, 65536));
+    return std::min(T, max_runs - done);
+}
+
+int bler_impl(polar_code_t *h, const int *devices, int n_dev, const double *ebno, int n_e, const uint8_t *Ls, int n_L,
+              long max_runs, long max_err, uint64_t seed, long batch, double *bler_out, double *ber_out, int *used_rccl) {
     if (!h || !ebno || !Ls || !bler_out) return fail(POLAR_E_ARG, "NULL argument");
-    if (n_e <= 0 || n_L <= 0 || max_runs <= 0 || batch < 0) return fail(POLAR_E_ARG, "bad sizes");
-    if (batch == 0) batch = std::min<long>(max_runs, 65536);       // default: bounded device memory, several rounds of waves
+    if (n_e <= 0 || n_L <= 0 || max_runs <= 0 || batch < 0 || n_dev < 1) return fail(POLAR_E_ARG, "bad sizes");
+    for (int i = 0; i < n_L; ++i)
+        if (Ls[i] < 1 || Ls[i] > POLAR_MAX_LIST) return fail(POLAR_E_ARG, "list size %d out of range", (int)Ls[i]);
     const int P = n_e * n_L;
-    std::vector<uint64_t> err(P, 0), run(P, 0);
+    std::vector<uint64_t> err(P, 0), bit(P, 0), run(P, 0);
     std::vector<uint8_t> en(P, 1);
-    for (long t0 = 0; t0 < max_runs; t0 += batch) {
-        long T = std::min(batch, max_runs - t0);
+    DevGuard dg_;
+    (void)hipGetDevice(&dg_.prev);
+    // one context (clone of the tables + scratch + stream) per device
+    std::vector<polar_code *> ctx(n_dev);
+    std::vector<hipStream_t> streams(n_dev, nullptr);
+    int ndev_visible = 0;
+    if (hipGetDeviceCount(&ndev_visible) != hipSuccess || ndev_visible <= 0)
+        return fail(POLAR_E_DEVICE, "no HIP device available; this library has no CPU decode path");
+    for (int d = 0; d < n_dev; ++d) {
+        const int dev = devices ? devices[d] : d;
+        if (dev < 0 || dev >= ndev_visible) return fail(POLAR_E_ARG, "device %d not visible (%d devices)", dev, ndev_visible);
+        for (int e = 0; e < d; ++e) if ((devices ? devices[e] : e) == dev) return fail(POLAR_E_ARG, "device %d listed twice", dev);
+        if (h->device < 0 && d == 0) h->device = dev;
+        ctx[d] = clone_on_device(h, dev);
+        DevGuard g2;
+        int rc = ensure_device(ctx[d], g2);
+        g2.prev = -1;
+        if (rc) return rc;
+        HIP_TRY(hipStreamCreateWithFlags(&streams[d], hipStreamNonBlocking));
+    }
+    auto cleanup = [&]() { for (int d = 0; d < n_dev; ++d) if (streams[d]) { (void)hipSetDevice(ctx[d]->device); (void)hipStreamDestroy(streams[d]); } };
+    // RCCL communicators (single process, one rank per device); without RCCL the counters are summed on the host
+    std::vector<void *> comms(n_dev, nullptr);
+    bool rccl = false;
+    if ((n_dev > 1 || getenv("POLAR_FORCE_RCCL")) && !getenv("POLAR_NO_RCCL") && g_rccl.load()) {
+        std::vector<int> devs(n_dev);
+        for (int d = 0; d < n_dev; ++d) devs[d] = ctx[d]->device;
+        rccl = (g_rccl.CommInitAll(comms.data(), n_dev, devs.data()) == 0);
+    }
+    if (used_rccl) *used_rccl = rccl ? 1 : 0;
+    int rc_all = POLAR_OK;
+    std::string err_msg;
+    for (long done = 0; done < max_runs;) {
         bool any = false;
         for (int i = 0; i < P; ++i) { en[i] = (err[i] <= (uint64_t)max_err); any |= en[i]; }   // :725
         if (!any) break;
-        int rc = polar_mc_batch(h, seed, (uint64_t)t0, T, 1, ebno, n_e, Ls, n_L, en.data(), err.data(), run.data());
-        if (rc) return rc;
+        const long T = next_round(batch, max_err, done, max_runs);       // trials of this round, all devices together
+        // device d simulates the trials done + d, done + d + n_dev, ... (counter-based inputs: the union does not
+        // depend on n_dev)
+        std::vector<int> rcs(n_dev, POLAR_OK);
+        std::vector<std::string> msgs(n_dev);
+        std::vector<long> Td(n_dev);
+        std::vector<std::vector<unsigned long long>> host_ctr(n_dev, std::vector<unsigned long long>((size_t)2 * P, 0));
+        auto worker = [&](int d) {
+            polar_code *c = ctx[d];
+            Td[d] = (T - d + n_dev - 1) / n_dev;
+            if (hipSetDevice(c->device) != hipSuccess) { rcs[d] = POLAR_E_DEVICE; msgs[d] = "hipSetDevice failed"; return; }
+            int rc = POLAR_OK;
+            if (Td[d] > 0)
+                rc = mc_round_launch(c, 0, seed, (uint64_t)(done + d), Td[d], n_dev, ebno, n_e, Ls, n_L, en.data(), streams[d]);
+            else
+                rc = (c->d_mc_ctr.ensure((size_t)2 * P) || hipMemsetAsync(c->d_mc_ctr.p, 0, (size_t)2 * P * 8, streams[d]) != hipSuccess) ? POLAR_E_DEVICE : POLAR_OK;
+            if (!rc && rccl) {
+                // sum of the round's counters over the devices (xGMI), in place on every device
+                if (g_rccl.AllReduce(c->d_mc_ctr.p, c->d_mc_ctr.p, (size_t)2 * P, kNcclUint64, kNcclSum, comms[d], streams[d]) != 0) {
+                    rc = POLAR_E_DEVICE; msgs[d] = "ncclAllReduce failed";
+                }
+            }
+            if (!rc && (!rccl || d == 0)) {
+                if (hipMemcpyAsync(host_ctr[d].data(), c->d_mc_ctr.p, (size_t)2 * P * 8, hipMemcpyDeviceToHost, streams[d]) != hipSuccess) rc = POLAR_E_DEVICE;
+            }
+            if (hipStreamSynchronize(streams[d]) != hipSuccess && !rc) { rc = POLAR_E_DEVICE; msgs[d] = "stream synchronize failed"; }
+            if (rc && msgs[d].empty()) msgs[d] = polar_last_error();
+            rcs[d] = rc;
+        };
+        if (n_dev == 1) worker(0);
+        else {
+            std::vector<std::thread> th;
+            for (int d = 0; d < n_dev; ++d) th.emplace_back(worker, d);
+            for (auto &t : th) t.join();
+        }
+        for (int d = 0; d < n_dev; ++d) if (rcs[d]) { rc_all = rcs[d]; err_msg = msgs[d]; }
+        if (rc_all) break;
+        for (int i = 0; i < P; ++i) {
+            if (!en[i]) continue;
+            for (int d = 0; d < (rccl ? 1 : n_dev); ++d) { err[i] += host_ctr[d][2 * i]; bit[i] += host_ctr[d][2 * i + 1]; }
+            run[i] += (uint64_t)T;
+        }
+        done += T;
     }
-    for (int i = 0; i < P; ++i) bler_out[i] = run[i] ? (double)err[i] / (double)run[i] : 0.0;    // :777-781
+    if (rccl) for (int d = 0; d < n_dev; ++d) if (comms[d]) (void)g_rccl.CommDestroy(comms[d]);
+    cleanup();
+    if (rc_all) return fail(rc_all, "%s", err_msg.c_str());
+    for (int i = 0; i < P; ++i) {
+        bler_out[i] = run[i] ? (double)err[i] / (double)run[i] : 0.0;                 // :777-781
+        if (ber_out) ber_out[i] = run[i] ? (double)bit[i] / (double)run[i] : 0.0;     // PolarM/PolarCode.m:848 (per run, as the reference)
+    }
     return POLAR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int polar_get_bler_quick(polar_code_t *h, const double *ebno, int n_e, const uint8_t *Ls, int n_L,
+                         long max_runs, long max_err, uint64_t seed, long batch, double *bler_out) {
+    if (!h) return fail(POLAR_E_ARG, "NULL argument");
+    int dev = h->device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return fail(POLAR_E_DEVICE, "no HIP device available; this library has no CPU decode path");
+    return bler_impl(h, &dev, 1, ebno, n_e, Ls, n_L, max_runs, max_err, seed, batch, bler_out, nullptr, nullptr);
+}
+int polar_get_bler_quick_ber(polar_code_t *h, const double *ebno, int n_e, const uint8_t *Ls, int n_L,
+                             long max_runs, long max_err, uint64_t seed, long batch, double *bler_out, double *ber_out) {
+    if (!h) return fail(POLAR_E_ARG, "NULL argument");
+    int dev = h->device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return fail(POLAR_E_DEVICE, "no HIP device available; this library has no CPU decode path");
+    return bler_impl(h, &dev, 1, ebno, n_e, Ls, n_L, max_runs, max_err, seed, batch, bler_out, ber_out, nullptr);
+}
+int polar_get_bler_quick_multi(polar_code_t *h, const int *devices, int n_dev, const double *ebno, int n_e,
+                               const uint8_t *Ls, int n_L, long max_runs, long max_err, uint64_t seed, long batch,
+                               double *bler_out, double *ber_out, int *used_rccl) {
+    return bler_impl(h, devices, n_dev, ebno, n_e, Ls, n_L, max_runs, max_err, seed, batch, bler_out, ber_out, used_rccl);
 }
 
 }  // extern "C"

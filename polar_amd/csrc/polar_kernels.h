@@ -27,6 +27,7 @@ struct PolarDecodeParams {
     uint8_t *flags;              // [B] device (ED kernels): 1 = decode this codeword again with the LLR-domain kernel
     const uint32_t *cw_list;     // work list of codeword indices (fallback pass), nullptr = 0..B-1
     const unsigned int *cw_count;// device: number of entries of cw_list (read by the kernel), nullptr = B
+    const unsigned int *n_dev;   // device: only the first min(B, *n_dev) codewords exist (Monte-Carlo alive lists), nullptr = B
 };
 
 size_t polar_decode_lds_bytes(int lds_log, int pipe);
@@ -37,8 +38,8 @@ hipError_t polar_launch_prefix_ed1(const PolarDecodeParams &p, hipStream_t st);
 hipError_t polar_launch_decode_llr_ed0(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, hipStream_t st);
 hipError_t polar_launch_decode_llr_ed1(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, hipStream_t st);
 hipError_t polar_launch_decode_llr(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, bool ed, hipStream_t st);
-hipError_t polar_launch_ed_front(const double *llr, double *ech, uint8_t *flags, const double *tabs, int N, long B, hipStream_t st);
-hipError_t polar_launch_ed_collect(const uint8_t *flags, long B, uint32_t *list, unsigned *count, hipStream_t st);
+hipError_t polar_launch_ed_front(const double *llr, double *ech, uint8_t *flags, const double *tabs, int N, long B, const unsigned *n_dev, hipStream_t st);
+hipError_t polar_launch_ed_collect(const uint8_t *flags, long B, const unsigned *n_dev, uint32_t *list, unsigned *count, hipStream_t st);
 
 hipError_t polar_launch_decode_p1(const PolarDecodeParams &p, int gs, int grid, hipStream_t st);
 
@@ -87,8 +88,17 @@ struct PolarEncodeParams {
     long info_block_div;         // info bits keyed by trial / info_block_div (100 = reference's refresh, 1 = every run)
     double *llr;                 // [B][N]
     uint8_t *info_out;           // [B][K] or nullptr
+    const unsigned int *n_dev;   // device: only the first min(B, *n_dev) rows exist (Monte-Carlo alive lists), nullptr = B
 };
 hipError_t polar_launch_encode(const PolarEncodeParams &p, hipStream_t st);
 hipError_t polar_launch_synth(const PolarEncodeParams &p, hipStream_t st);   // BPSK or ASK/BICM by p.constellation
 hipError_t polar_launch_count_errors(const uint8_t *a, const uint8_t *b, long B, int K,
                                      unsigned long long *err, uint8_t *mismatch_flags, hipStream_t st);
+// Monte-Carlo round on the device (PolarCode.cpp:728-742, 758-769): alive[i] = t0 + i*stride, *n = T
+hipError_t polar_launch_mc_init_alive(uint64_t *alive, unsigned *n, uint64_t t0, long stride, long T, hipStream_t st);
+// rows [0, min(B, *n_in)): block error iff decoded != sent; ctr[0] += block errors, ctr[1] += differing bits
+// (PolarM/PolarCode.m:836-840); the trials in error are appended to alive_out / *n_out (the others were decoded
+// correctly and are "counted, not simulated" at the higher Eb/N0 points)
+hipError_t polar_launch_mc_count_compact(const uint8_t *decoded, const uint8_t *sent, long B, int K,
+                                         const uint64_t *alive_in, const unsigned *n_in, uint64_t *alive_out, unsigned *n_out,
+                                         unsigned long long *ctr, hipStream_t st);

@@ -400,7 +400,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     auto GN = [&](double a, double b, uint32_t cw_, int bi) -> double {
         if constexpr (ED) return g_node_e(a, b, cw_ << (31 - bi), tb); else return g_node(a, b, (cw_ >> bi) & 1u);
     };
-    const long Bv = p.cw_count ? (long)*p.cw_count : p.B;      // (fallback pass: codewords come from p.cw_list)
+    // (fallback pass: codewords come from p.cw_list; Monte-Carlo: only the first *p.n_dev rows are alive)
+    const long Bv = p.cw_count ? (long)*p.cw_count : (p.n_dev ? ((long)*p.n_dev < p.B ? (long)*p.n_dev : p.B) : p.B);
 
     // per-wave global scratch
     const size_t big_elems = (N > 2 * SL) ? (size_t)(N - 2 * SL) : 0;
@@ -1267,9 +1268,10 @@ __global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p) {
     const int n = p.n, N = p.N, Q = p.prefix_q, Pe = p.prefix_len;
     const int R = Q >> 5;
     const long per_block = 8;
-    for (long c0 = (long)blockIdx.x * per_block; c0 < p.B; c0 += (long)gridDim.x * per_block) {
+    const long Bv = p.n_dev ? ((long)*p.n_dev < p.B ? (long)*p.n_dev : p.B) : p.B;
+    for (long c0 = (long)blockIdx.x * per_block; c0 < Bv; c0 += (long)gridDim.x * per_block) {
         const long cw = c0 + (threadIdx.x >> 5);
-        const bool valid = cw < p.B;
+        const bool valid = cw < Bv;
         const double *in0 = p.llr + (size_t)(valid ? cw : 0) * N;
         double *pre = const_cast<double *>(p.pre) + (size_t)(valid ? cw : 0) * (size_t)(N - Q + 1);
         double x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1370,7 +1372,8 @@ hipError_t polar_launch_prefix(const PolarDecodeParams &p, bool ed, hipStream_t 
 // ed_front_kernel — channel LLRs -> stored form of the exp-domain kernel (p.llr -> p.ech), plus the
 // input guard: flags[cw] = 1 when the codeword holds a non-finite LLR or one below 1e-9 (the
 // reference's f-node results are then its own rounding noise), else 0.
-__global__ __launch_bounds__(256) void ed_front_kernel(const double *llr, double *ech, uint8_t *flags, const double *tabs_g, int N, long B) {
+__global__ __launch_bounds__(256) void ed_front_kernel(const double *llr, double *ech, uint8_t *flags, const double *tabs_g, int N, long B, const unsigned *n_dev) {
+    if (n_dev && (long)*n_dev < B) B = (long)*n_dev;
     __shared__ double tabs[324];
     for (int i = threadIdx.x; i < 322; i += 256) tabs[i] = tabs_g[i];
     __syncthreads();
@@ -1389,21 +1392,22 @@ __global__ __launch_bounds__(256) void ed_front_kernel(const double *llr, double
         if (lane == 0) flags[cw] = bad ? 1 : 0;
     }
 }
-hipError_t polar_launch_ed_front(const double *llr, double *ech, uint8_t *flags, const double *tabs, int N, long B, hipStream_t st) {
+hipError_t polar_launch_ed_front(const double *llr, double *ech, uint8_t *flags, const double *tabs, int N, long B, const unsigned *n_dev, hipStream_t st) {
     long blocks = (B + 3) / 4;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(ed_front_kernel, dim3((unsigned)blocks), dim3(256), 0, st, llr, ech, flags, tabs, N, B);
+    hipLaunchKernelGGL(ed_front_kernel, dim3((unsigned)blocks), dim3(256), 0, st, llr, ech, flags, tabs, N, B, n_dev);
     return hipGetLastError();
 }
 // flagged codewords -> work list of the fallback pass (order irrelevant: every codeword is independent)
-__global__ __launch_bounds__(256) void ed_collect_kernel(const uint8_t *flags, long B, uint32_t *list, unsigned *count) {
+__global__ __launch_bounds__(256) void ed_collect_kernel(const uint8_t *flags, long B, const unsigned *n_dev, uint32_t *list, unsigned *count) {
+    if (n_dev && (long)*n_dev < B) B = (long)*n_dev;
     for (long cw = (long)blockIdx.x * 256 + threadIdx.x; cw < B; cw += (long)gridDim.x * 256)
         if (flags[cw]) list[atomicAdd(count, 1u)] = (uint32_t)cw;
 }
-hipError_t polar_launch_ed_collect(const uint8_t *flags, long B, uint32_t *list, unsigned *count, hipStream_t st) {
+hipError_t polar_launch_ed_collect(const uint8_t *flags, long B, const unsigned *n_dev, uint32_t *list, unsigned *count, hipStream_t st) {
     long blocks = (B + 255) / 256;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(ed_collect_kernel, dim3((unsigned)blocks), dim3(256), 0, st, flags, B, list, count);
+    hipLaunchKernelGGL(ed_collect_kernel, dim3((unsigned)blocks), dim3(256), 0, st, flags, B, n_dev, list, count);
     return hipGetLastError();
 }
 

@@ -41,40 +41,28 @@ classdef PolarCode < handle
             obj.cc_parameter = design_epsilon;
             obj.cc_misc = '';
         end
-        function monte_carlo_code_construction(obj, design_snr_db, num_runs, constellation_name, receiver_algo, seed)
-            % Same name, arguments and defaults as PolarM/PolarCode.m:95-141; the genie-aided SC runs
-            % on the GPU (polar_mc_construction), the table is cached in CodeConstructionData/ under the
-            % reference's file name and format.
-            if (nargin < 3) || isempty(num_runs), num_runs = 100e3; end
-            if (nargin < 4) || isempty(constellation_name), constellation_name = 'bpsk'; end
-            if (nargin < 5) || isempty(receiver_algo), receiver_algo = 'bicm'; end
-            if nargin < 6, seed = 1; end
-            if ~strcmp(receiver_algo, 'bicm'), error('only the bicm receiver is built'); end
-            ids = struct('bpsk', 4, 'ask4_gray', 1, 'ask8_gray', 2, 'ask16_gray', 3);
-            cid = ids.(strrep(constellation_name, '-', '_'));
-            obj.cc_method = 'monte-carlo';
-            obj.cc_parameter = design_snr_db;
-            obj.cc_misc = [constellation_name, '_', receiver_algo, '_', num2str(num_runs)];
-            txt_file_name = ['CodeConstructionData/MC_block_length_', obj.get_unique_string(), '.txt'];
-            if exist(txt_file_name, 'file')
-                channels = load(txt_file_name);
-            else
-                channels = polar_mex('mc_construction', obj.n, cid, design_snr_db, seed, num_runs);
-                fileID = fopen(txt_file_name, 'w');
-                if fileID > 0
-                    fprintf(fileID, '%d \n', channels);
-                    fclose(fileID);
-                end
-            end
-            [~, channel_order] = sort(channels(:)', 'ascend');          % MATLAB's sort is stable
-            n_info = obj.info_length + obj.crc_size;
-            obj.info_bits = channel_order(1:n_info);
-            obj.frozen_bits = ones(1, obj.block_length);
-            obj.frozen_bits(obj.info_bits) = 0;
-            polar_mex('destroy', obj.h);
-            obj.h = polar_mex('create_explicit', obj.n, obj.info_length, obj.crc_size, uint8(obj.frozen_bits), ...
-                              uint16(channel_order - 1), uint8(obj.crc_matrix));
-            disp(['Monte carlo code construction done. Bler estimate = ', num2str(sum(channels(obj.info_bits)) / num_runs)]);
+        function monte_carlo_code_construction(obj, design_snr_db, varargin)
+            % monte_carlo_code_construction(design_snr_db [, num_runs, constellation_name, receiver_algo, seed])
+            % Same method name, argument order and defaults as the reference class (PolarM/PolarCode.m:95); the
+            % design itself — genie-aided SC error counting on the GPU, the reference's table cache file, the
+            % stable reliability sort and the new decoder handle — is ONE gateway call ('monte_carlo_design').
+            opt = [varargin, cell(1, 4 - numel(varargin))];
+            defaults = {100e3, 'bpsk', 'bicm', 1};
+            unset = cellfun(@isempty, opt);
+            opt(unset) = defaults(unset);
+            [num_runs, constellation_name, receiver_algo, seed] = opt{:};
+            assert(strcmp(receiver_algo, 'bicm'), 'only the bicm receiver is built');
+            cid = find(strcmp(constellation_name, {'ask4-gray', 'ask8-gray', 'ask16-gray', 'bpsk'}));   % POLAR_CONST_*
+            [obj.cc_method, obj.cc_parameter] = deal('monte-carlo', design_snr_db);
+            obj.cc_misc = sprintf('%s_%s_%s', constellation_name, receiver_algo, num2str(num_runs));
+            table_file = fullfile('CodeConstructionData', ['MC_block_length_', obj.get_unique_string(), '.txt']);
+            old = obj.h;
+            [obj.h, fz, order0, est] = polar_mex('monte_carlo_design', obj.n, obj.info_length, obj.crc_size, ...
+                uint8(obj.crc_matrix), cid, design_snr_db, num_runs, seed, table_file);
+            polar_mex('destroy', old);
+            obj.frozen_bits = double(fz);
+            obj.info_bits = double(order0(1 : obj.info_length + obj.crc_size)) + 1;
+            fprintf('Monte carlo code construction done. Bler estimate = %g\n', est);
         end
         function unique_string = get_unique_string(obj)                % PolarM :258-261
             unique_string = [num2str(obj.block_length), '_', num2str(length(obj.info_bits)), ...
@@ -99,14 +87,17 @@ classdef PolarCode < handle
             % llr may be 1 x N or B x N (one codeword per row): rows are decoded as one GPU batch
             u = double(polar_mex('decode_scl_llr', obj.h, double(llr), list_size));
         end
-        function [bler, ber] = get_bler_quick(obj, ebno_vec, list_size_vec, max_runs, max_err, seed)
-            % bler(i_ebno, i_list) as PolarM (:781-850); PolarM constants max_err=50, max_runs=500 (:788-789)
+        function [bler, ber] = get_bler_quick(obj, ebno_vec, list_size_vec, max_runs, max_err, seed, devices)
+            % [bler, ber] indexed (i_ebno, i_list) as PolarM (:781-850); PolarM constants max_err=50, max_runs=500
+            % (:788-789); ber = bit errors per run as the reference computes it (:848). devices (optional): GPU
+            % ids to shard the trials over (one process, RCCL all-reduce of the counters).
             if nargin < 4, max_runs = 500; end
             if nargin < 5, max_err = 50; end
             if nargin < 6, seed = 1; end
-            b = polar_mex('get_bler_quick', obj.h, double(ebno_vec(:)'), uint8(list_size_vec(:)'), max_runs, max_err, seed);
+            if nargin < 7, devices = []; end
+            [b, e] = polar_mex('get_bler_quick', obj.h, double(ebno_vec(:)'), uint8(list_size_vec(:)'), max_runs, max_err, seed, int32(devices));
             bler = b';      % gateway returns [n_L x n_e] (PolarC layout); PolarM indexes (ebno, list)
-            ber = [];       % the reference's BER output is not produced by the GPU engine
+            ber = e';
         end
         % names used by the project brief
         function u = decode_SC_P1(obj, p1), u = obj.decode_sc_p1(p1); end

@@ -1,6 +1,8 @@
 // polar_mex.cpp — MEX gateway: command string + uint64 handle -> C-ABI (include/polar_amd.h).
 // Build (needs MATLAB, not available in the build image — source delivered):
 //   mex -I<repo>/include polar_mex.cpp -L<repo>/polar_amd -lpolar_amd
+#include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -54,6 +56,58 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         for (size_t i = 0; i < cnt.size(); ++i) mxGetPr(plhs[0])[i] = (double)cnt[i];
         return;
     }
+    if (c == "monte_carlo_design") {
+        // [h, frozen, order0, bler_est] = polar_mex('monte_carlo_design', n, K, crc, crc_matrix, constellation_id,
+        //                                           design_snr_db, num_runs, seed, table_file)
+        // The whole design step in one call: per-channel error counts from `table_file` when it exists (the
+        // reference's cache format, one '%d ' per line), else from the GPU (polar_mc_construction) and written
+        // there; reliability order = stable ascending sort of the counts; explicit-table handle.
+        const int n_ = (int)mxGetScalar(prhs[1]), K_ = (int)mxGetScalar(prhs[2]), crc_ = (int)mxGetScalar(prhs[3]);
+        const size_t N_ = (size_t)1 << n_;
+        char path[1024] = "";
+        if (nrhs > 9 && mxIsChar(prhs[9])) mxGetString(prhs[9], path, sizeof path);
+        std::vector<uint64_t> cnt(N_, 0);
+        bool have = false;
+        if (path[0]) {
+            if (FILE *f = fopen(path, "r")) {
+                size_t k = 0;
+                double v;
+                while (k < N_ && fscanf(f, "%lf", &v) == 1) cnt[k++] = (uint64_t)v;
+                fclose(f);
+                have = (k == N_);
+            }
+        }
+        const long runs = (long)mxGetScalar(prhs[7]);
+        if (!have) {
+            check(polar_mc_construction(n_, (int)mxGetScalar(prhs[5]), mxGetScalar(prhs[6]), (uint64_t)mxGetScalar(prhs[8]), 0, runs, 0, cnt.data()));
+            if (path[0]) {
+                if (FILE *f = fopen(path, "w")) {
+                    for (size_t i = 0; i < N_; ++i) fprintf(f, "%llu \n", (unsigned long long)cnt[i]);
+                    fclose(f);
+                }
+            }
+        }
+        std::vector<uint16_t> order(N_);
+        for (size_t i = 0; i < N_; ++i) order[i] = (uint16_t)i;
+        std::stable_sort(order.begin(), order.end(), [&](uint16_t a, uint16_t b) { return cnt[a] < cnt[b]; });
+        std::vector<uint8_t> frozen(N_, 1), m((size_t)crc_ * K_);
+        double est = 0;
+        for (int i = 0; i < K_ + crc_; ++i) { frozen[order[i]] = 0; est += (double)cnt[order[i]]; }
+        if (crc_ > 0) {
+            const uint8_t *d = (const uint8_t *)mxGetData(prhs[4]);           // column-major crc x K
+            for (int i = 0; i < crc_; ++i)
+                for (int j = 0; j < K_; ++j) m[(size_t)i * K_ + j] = d[(size_t)j * crc_ + i];
+        }
+        polar_code_t *h = nullptr;
+        check(polar_create_explicit(n_, K_, crc_, frozen.data(), order.data(), crc_ > 0 ? m.data() : nullptr, &h));
+        mexLock();
+        plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
+        *(uint64_t *)mxGetData(plhs[0]) = (uint64_t)(uintptr_t)h;
+        if (nlhs > 1) { plhs[1] = mxCreateNumericMatrix(1, N_, mxUINT8_CLASS, mxREAL); memcpy(mxGetData(plhs[1]), frozen.data(), N_); }
+        if (nlhs > 2) { plhs[2] = mxCreateNumericMatrix(1, N_, mxUINT16_CLASS, mxREAL); memcpy(mxGetData(plhs[2]), order.data(), 2 * N_); }
+        if (nlhs > 3) plhs[3] = mxCreateDoubleScalar(est / (double)runs);
+        return;
+    }
     polar_code_t *h = H(prhs[1]);
     int n, N, K, crc;
     check(polar_get_params(h, &n, &N, &K, &crc));
@@ -95,15 +149,26 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         plhs[0] = mxCreateDoubleMatrix(1, K, mxREAL);
         check(polar_decode_sc_p1(h, mxGetPr(prhs[2]), mxGetPr(plhs[0])));
     } else if (c == "get_bler_quick") {
+        // [bler, ber] = polar_mex('get_bler_quick', h, ebno(1 x n_e), L(uint8 1 x n_L), max_runs, max_err, seed [, devices(int32)])
+        // both outputs n_L x n_e (PolarC layout); with a device list the trials are sharded over those GPUs
         int n_e = (int)mxGetNumberOfElements(prhs[2]), n_L = (int)mxGetNumberOfElements(prhs[3]);
         long max_runs = (long)mxGetScalar(prhs[4]), max_err = (long)mxGetScalar(prhs[5]);
         uint64_t seed = (uint64_t)mxGetScalar(prhs[6]);
-        std::vector<double> b((size_t)n_e * n_L);
-        check(polar_get_bler_quick(h, mxGetPr(prhs[2]), n_e, (const uint8_t *)mxGetData(prhs[3]), n_L, max_runs,
-                                   max_err, seed, max_runs, b.data()));
+        std::vector<double> b((size_t)n_e * n_L), e((size_t)n_e * n_L);
+        if (nrhs > 7 && mxGetNumberOfElements(prhs[7]) > 0)
+            check(polar_get_bler_quick_multi(h, (const int *)mxGetData(prhs[7]), (int)mxGetNumberOfElements(prhs[7]), mxGetPr(prhs[2]), n_e,
+                                             (const uint8_t *)mxGetData(prhs[3]), n_L, max_runs, max_err, seed, 0, b.data(), e.data(), nullptr));
+        else
+            check(polar_get_bler_quick_ber(h, mxGetPr(prhs[2]), n_e, (const uint8_t *)mxGetData(prhs[3]), n_L, max_runs,
+                                           max_err, seed, 0, b.data(), e.data()));
         plhs[0] = mxCreateDoubleMatrix(n_L, n_e, mxREAL);
         double *d = mxGetPr(plhs[0]);
-        for (int l = 0; l < n_L; ++l) for (int e = 0; e < n_e; ++e) d[(size_t)e * n_L + l] = b[(size_t)l * n_e + e];
+        for (int l = 0; l < n_L; ++l) for (int i = 0; i < n_e; ++i) d[(size_t)i * n_L + l] = b[(size_t)l * n_e + i];
+        if (nlhs > 1) {
+            plhs[1] = mxCreateDoubleMatrix(n_L, n_e, mxREAL);
+            double *d2 = mxGetPr(plhs[1]);
+            for (int l = 0; l < n_L; ++l) for (int i = 0; i < n_e; ++i) d2[(size_t)i * n_L + l] = e[(size_t)l * n_e + i];
+        }
     } else {
         mexErrMsgIdAndTxt("polar_amd:cmd", "unknown command %s", cmd);
     }

@@ -22,6 +22,19 @@ def _p(a, t):
     return a.ctypes.data_as(t)
 
 
+def usable_cpus():
+    """Host cores this process may actually use: the cgroup CPU quota when there is one (the GPU boxes report 256
+    logical CPUs but run the container on a 16-CPU quota), else the affinity mask / CPU count."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
 def build_oracle():
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "all"])
 

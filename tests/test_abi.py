@@ -115,3 +115,13 @@ def test_construction_file_loader(built_lib, tmp_path):
     g = polar_amd.PolarCode.from_construction_file(str(f), 512)
     c, frozen, order, crcm = G.tables("cfg5_n10_k512_ask16")
     assert (g.frozen_bits == frozen).all() and (g.channel_order_descending == order).all()
+
+
+def test_mex_gateway_compiles_syntax_only():
+    """COMPILE-ONLY check of the MEX gateway source against a minimal mex.h stand-in (tests/mex_stub/mex.h):
+    it catches syntax/signature drift between polar_mex.cpp and include/polar_amd.h. It is NOT a binding test —
+    MATLAB is not in the image, the gateway is never linked or run."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(root, "tests", "mex_stub"),
+                           "-I", os.path.join(root, "include"), os.path.join(root, "polar_amd", "matlab", "polar_mex.cpp")])

@@ -1,5 +1,5 @@
 """CPU suite: the multi-GPU Monte-Carlo sharding logic (polar_amd/montecarlo.py) under
-torch.distributed with the gloo backend, world_size 2. The per-rank engine is the CPU oracle
+torch.distributed with the gloo backend, world_size 2 and 4. The per-rank engine is the CPU oracle
 (test-only) standing in for the GPU engine: the sharded counters must equal the unsharded ones
 exactly, because the synthetic trials are counter-based."""
 import os
@@ -54,6 +54,8 @@ def test_sharded_counters_equal_unsharded(oracle_built, tmp_path):
     a = _run(1, tmp_path)
     b = _run(2, tmp_path)
     assert a == b
+    c = _run(4, tmp_path)          # 24 trials per round over 4 ranks, 75 construction runs over 4 ranges
+    assert a == c
     run = np.array(a["run"])
     err = np.array(a["err"])
     assert run.max() <= 96 and (err <= run).all() and run.min() >= 24

@@ -1,0 +1,93 @@
+"""GPU: the Monte-Carlo engine behind get_bler_quick (PolarCode.cpp:658-785; PolarM/PolarCode.m:781-850) —
+the device-side rounds, PolarM's `ber` output, the early-stop rounds, and the single-process multi-GPU entry point
+(polar_get_bler_quick_multi) driven through RCCL with one device."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(n, K, crc):
+    import polar_amd
+    from oracle_lib import Oracle
+    o = Oracle(n, K, 0.32, crc, srand=1)
+    C.CDLL(None).srand(C.c_uint(1))
+    return o, polar_amd.PolarCode(n, K, 0.32, crc)
+
+
+def test_ber_is_bit_errors_per_run_as_polarm(built_lib, oracle_built):
+    """One (L, Eb/N0) point, nothing stops early: every trial is simulated, so
+    ber = sum(differing info bits) / runs and bler = block errors / runs, both computable from the oracle's
+    decodes of the same counter-based trials (PolarM/PolarCode.m:836-848: per run, not per bit)."""
+    o, g = _pair(8, 128, 4)
+    T, L, ebno, seed = 300, 4, 1.0, 77
+    llr, info = o.synth_llr(seed, 0, T, o.snr_sqrt_linear(ebno))
+    dec = o.decode_scl_llr(llr, L)
+    nd = (dec != info).sum(axis=1)
+    bler, ber = g.get_bler_quick([ebno], [L], max_runs=T, max_err=10**9, seed=seed, batch=T, return_ber=True)
+    assert bler[0, 0] == (nd > 0).sum() / T
+    assert ber[0, 0] == nd.sum() / T
+    assert ber[0, 0] > bler[0, 0] > 0
+    # step-wise form with the bit-error accumulator
+    e, b, r = (np.zeros((1, 1), np.uint64) for _ in range(3))
+    g.mc_batch_ber(seed, 0, T, 1, [ebno], [L], np.ones((1, 1), np.uint8), e, b, r)
+    assert (int(e[0, 0]), int(b[0, 0]), int(r[0, 0])) == (int((nd > 0).sum()), int(nd.sum()), T)
+
+
+def test_default_rounds_respect_max_err(built_lib, oracle_built):
+    """Reference defaults (1000 runs, 100 errors): the library's own rounds (batch = 0) must stop a high-BLER point
+    early — run count well below max_runs — and leave low-BLER points at max_runs; the estimate stays consistent
+    with the all-trials estimate."""
+    o, g = _pair(8, 128, 0)
+    ebno = [0.0, 6.0]
+    full = g.get_bler_quick(ebno, [1], max_runs=1000, max_err=10**9, seed=3, batch=1000)
+    auto = g.get_bler_quick(ebno, [1], max_runs=1000, max_err=100, seed=3)
+    assert full[0, 0] > 0.3                                   # > 100 errors long before 1000 runs
+    # geometric rounds 256, 256, 512: the 0 dB point stops after the first round(s); same trials => the prefix estimate
+    first = g.get_bler_quick(ebno, [1], max_runs=256, max_err=10**9, seed=3, batch=256)
+    assert auto[0, 0] == first[0, 0]
+    assert auto[0, 1] == full[0, 1]                           # the clean point ran all 1000 trials
+    # batch = 1 reproduces the reference's per-run granularity: stops right after the (max_err+1)-th error
+    one = g.get_bler_quick([0.0], [1], max_runs=400, max_err=20, seed=3, batch=1)
+    runs = round(21 / one[0, 0])
+    assert abs(21 / runs - one[0, 0]) < 1e-12 and runs < 400
+
+
+def test_multi_gpu_entry_point_one_device_through_rccl(built_lib, oracle_built):
+    """polar_get_bler_quick_multi with n_dev = 1 and the RCCL path forced: the counters go through
+    ncclAllReduce(uint64, sum) and must equal the single-GPU entry point exactly (bler and ber)."""
+    o, g = _pair(9, 256, 8)
+    ebno, Ls = [1.0, 2.0, 3.0], [1, 8]
+    want, want_ber = g.get_bler_quick(ebno, Ls, max_runs=600, max_err=40, seed=9, batch=200, return_ber=True)
+    os.environ["POLAR_FORCE_RCCL"] = "1"
+    try:
+        got, got_ber = g.get_bler_quick(ebno, Ls, max_runs=600, max_err=40, seed=9, batch=200, return_ber=True, devices=[0])
+        used = g.last_used_rccl
+    finally:
+        del os.environ["POLAR_FORCE_RCCL"]
+    assert used, "RCCL could not be loaded/initialised on the GPU box"
+    assert (got == want).all() and (got_ber == want_ber).all()
+    # and the host-sum fallback
+    os.environ["POLAR_NO_RCCL"] = "1"
+    try:
+        got2 = g.get_bler_quick(ebno, Ls, max_runs=600, max_err=40, seed=9, batch=200, devices=[0])
+        assert not g.last_used_rccl
+    finally:
+        del os.environ["POLAR_NO_RCCL"]
+    assert (got2 == want).all()
+
+
+def test_handle_keeps_callers_device_and_rejects_bad_devices(built_lib):
+    import torch
+    import polar_amd
+    g = polar_amd.PolarCode(7, 64, 0.32, 0)
+    assert torch.cuda.current_device() == 0
+    with pytest.raises(polar_amd.PolarError):
+        g.get_bler_quick([1.0], [1], max_runs=10, devices=[0, 0])
+    with pytest.raises(polar_amd.PolarError):
+        g.get_bler_quick([1.0], [1], max_runs=10, devices=[torch.cuda.device_count()])
+    with pytest.raises(polar_amd.PolarError):
+        g.set_tuning(8, 2)          # lds_log = 2 exists only for the 4-wave-block kernels

@@ -2,8 +2,8 @@
   * >= 100 000 codewords at two SNRs, batches larger than one round of the persistent grid (dynamic work
     hand-out, prefix kernel, exp-domain kernel + fallback pass all exercised), bit-exact against the CPU
     side running on all host cores (the unmodified reference build oracle/_ref when it travelled with the
-    snapshot — it allocates ~800 arrays per decode, so it is kept to 64 threads x 128 codewords per SNR — and the
-    C restatement (flat arenas, scales to every core) on all of them; one decoder object per thread);
+    snapshot, on a 4 096-codeword slice per SNR, and the C restatement on all of them; one decoder object per
+    thread, two threads per usable core — the GPU boxes give the container a 16-CPU quota);
   * the exp-domain kernel against the LLR-domain kernel on 4 x 65 536 further codewords (GPU vs GPU)."""
 import ctypes as C
 import os
@@ -29,10 +29,10 @@ def test_headline_config_100k_codewords_vs_cpu(built_lib, oracle_built):
     import oracle_lib
     g = _gpu_code()
     N = 1 << N_LOG2
-    cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 192))
-    # ~130 codewords/s per host core: 51 200 per SNR needs ~2 s on 192 threads; scale down on small hosts
-    per_snr = 51200 if threads >= 64 else max(512, 40 * threads)
+    cores = oracle_lib.usable_cpus()          # (cgroup quota: 16 on the GPU boxes, whatever os.cpu_count() says)
+    threads = 2 * cores
+    # ~150 codewords/s per host core: 2 x 51 200 codewords need ~45 s on 16 cores; scale down on smaller hosts
+    per_snr = 51200 if cores >= 16 else max(512, 1500 * cores)
     use_ref = oracle_lib.have_reference()
     total_bad = 0
     total = 0
@@ -74,13 +74,13 @@ def test_headline_config_100k_codewords_vs_cpu(built_lib, oracle_built):
         total += B
         assert bad == 0, f"{bad}/{B} codewords differ from the CPU restatement at Eb/N0 = {ebno} dB"
         if use_ref:
-            rows = min(B, 8192 if threads >= 64 else 256)
-            want_ref = cpu_decode(oracle_lib.Reference, rows, min(threads, 64))
+            rows = min(B, 4096 if cores >= 16 else 256)
+            want_ref = cpu_decode(oracle_lib.Reference, rows, threads)
             bad = int((want_ref != got[:rows]).any(axis=1).sum())
             assert bad == 0, f"{bad}/{rows} codewords differ from the unmodified reference at Eb/N0 = {ebno} dB"
     print(f"{total} codewords, {total_bad} mismatches, {time.time() - t_start:.1f} s, "
           f"CPU side: restatement on {threads} threads" + (" + unmodified reference on a slice" if use_ref else ""))
-    if threads >= 64:
+    if cores >= 16:
         assert total >= 100000
 
 
