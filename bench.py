@@ -25,9 +25,7 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
-# rate at which the decode kernel itself streams its state with the exact f-node compiled out
-# (measurement build POLAR_EXPERIMENT_NO_EXACT_F): the traffic floor of this design
-STREAM_PATTERN_GBS = 5870.0
+LDS_PEAK_GBS = 256 * 128 * 2.4    # 256 CUs x 128 B/clk x 2.4 GHz ~ 78.6 TB/s
 
 
 def main():
@@ -45,6 +43,7 @@ def main():
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--lds-log", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="codewords for the CPU baseline (-1 = auto, 0 = skip)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short timings of BASELINE.json configs 1, 2, 3, 5")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -172,13 +171,30 @@ def main():
             # committed PMC profile over the LIVE kernel time, and the profile's fp64 VALU occupancy
             "traffic_rate_GBps": (traffic / kern_avg_s / 1e9) if traffic else None,
             "traffic_frac_of_peak": (traffic / kern_avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-            "traffic_frac_of_traffic_floor_rate": (traffic / kern_avg_s / 1e9 / STREAM_PATTERN_GBS) if traffic else None,
-            "valu_busy_frac_in_profile": prof.get("valu_busy_frac_in_profile"),
         },
+    }
+    # the two other rooflines of this path, and the LDS-vs-HBM byte split ("LDS-hit fraction").
+    # LDS bytes are MODELLED from the schedule (every node of the layers of size <= 8 writes 8 B per path, every node
+    # whose source layer is LDS-resident reads 2 x 8 B; register-chained visits read less: an upper bound), HBM
+    # bytes and the VALU occupancy come from the committed rocprofv3 PMC profile of this very command.
+    lds_layers_w, lds_layers_r = 4, 3                       # layers written to / read from LDS (S <= 8 / S <= 4)
+    lds_bytes = B * L * N * 8.0 * (lds_layers_w + 2 * lds_layers_r)
+    res["roofline"]["lds"] = {
+        "modelled_bytes_per_launch": lds_bytes, "achieved": lds_bytes / kern_avg_s / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
+        "frac": lds_bytes / kern_avg_s / 1e9 / LDS_PEAK_GBS,
+        "lds_hit_fraction": (lds_bytes / (lds_bytes + traffic)) if traffic else None,
+        "note": "modelled upper bound; lds_hit_fraction = LDS bytes / (LDS + measured HBM bytes) of the decoder's working state",
+    }
+    res["roofline"]["valu"] = {
+        "busy_frac_in_profile": prof.get("valu_busy_frac_in_profile"),
+        "valu_insts_per_wave_decode_in_profile": prof.get("valu_insts_per_wave_decode"),
+        "note": "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles), committed profile (profiles/traffic.json)",
     }
 
     if rank == 0 and world == 1 and args.cpu_sample != 0:
         res["cpu_baseline"] = cpu_baseline(args, code, llr, out)
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        res["other_configs"] = other_configs(args, dev)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -226,6 +242,28 @@ def cpu_baseline(args, code, llr, out):
     ref_out = cpu.decode_scl_llr(h, args.L)
     dt = time.perf_counter() - t
     mism = int((ref_out != out[:sample].cpu().numpy()).any(axis=1).sum())
+    # all usable host cores: independent per-thread decoder objects on a second bounded sample
+    import threading
+    cores = oracle_lib.usable_cpus()
+    threads = 2 * cores
+    sample2 = int(max(threads, min(llr.shape[0], 10.0 * (sample / dt) * cores * 0.8)))
+    h2 = llr[:sample2].cpu().numpy()
+    want2 = np.zeros((sample2, args.K), np.uint8)
+    crcm = code.crc_matrix
+
+    def work(t):
+        c = (oracle_lib.Reference if kind == "reference" else oracle_lib.Oracle)(args.n, args.K, 0.32, args.crc)
+        c.set_crc_matrix(crcm)
+        sl = slice(t * sample2 // threads, (t + 1) * sample2 // threads)
+        if sl.stop > sl.start:
+            want2[sl] = c.decode_scl_llr(h2[sl], args.L)
+
+    t = time.perf_counter()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    dt2 = time.perf_counter() - t
+    mism2 = int((want2 != out[:sample2].cpu().numpy()).any(axis=1).sum())
     return {
         "value": sample / dt,
         "unit": "codewords/s",
@@ -234,7 +272,46 @@ def cpu_baseline(args, code, llr, out):
         "kind": kind,
         "sample": f"first {sample} codewords of the benchmark batch, decode_scl_llr only, single thread",
         "gpu_vs_cpu_mismatching_codewords": mism,
+        "all_cores": {
+            "value": sample2 / dt2, "unit": "codewords/s", "cores": cores, "threads": threads,
+            "nproc": os.cpu_count(), "note": "cores = cgroup CPU quota of the container (the box reports nproc logical CPUs)",
+            "sample": f"first {sample2} codewords of the benchmark batch, one decoder object per thread",
+            "gpu_vs_cpu_mismatching_codewords": mism2,
+        },
     }
+
+
+def other_configs(args, dev):
+    """Short kernel+count timings of the other BASELINE.json configurations in the same run (same library, same
+    box): not the headline metric, three steps each on device-generated trials."""
+    import ctypes as C
+    import polar_amd
+    outs = []
+    for name, n, K, crc, L, B, ebno in (("config 1 code (N=512 K=256 L=1)", 9, 256, 0, 1, 262144, 2.0),
+                                        ("config 2 (N=2048 K=1024 L=1 SC)", 11, 1024, 0, 1, 65536, 2.0),
+                                        ("config 2, batch 262144", 11, 1024, 0, 1, 262144, 2.0),
+                                        ("config 3 (N=2048 K=1024 crc16 L=4)", 11, 1024, 16, 4, 65536, 2.0),
+                                        ("config 5 code (N=1024 K=512 L=8)", 10, 512, 0, 8, 65536, 2.0)):
+        C.CDLL(None).srand(C.c_uint(1))
+        c = polar_amd.PolarCode(n, K, 0.32, crc)
+        Nn = 1 << n
+        llr = torch.empty((B, Nn), dtype=torch.float64, device=dev)
+        sent = torch.empty((B, K), dtype=torch.uint8, device=dev)
+        out = torch.empty((B, K), dtype=torch.uint8, device=dev)
+        cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+        c.synth_llr_dev(args.seed, 0, B, c.snr_sqrt_linear(ebno), llr.data_ptr(), sent.data_ptr())
+        for it in range(4):
+            if it == 1:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            c.decode_scl_llr_dev(llr.data_ptr(), B, L, out.data_ptr())
+            c.count_errors_dev(out.data_ptr(), sent.data_ptr(), B, cnt.data_ptr())
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        outs.append({"config": name, "batch": B, "ebno_db": ebno, "value": B / dt, "unit": "codewords/s",
+                     "ms_per_step": dt * 1e3, "block_errors_per_step": int(cnt[0].item()) // 4})
+        del llr, sent, out
+    return outs
 
 
 if __name__ == "__main__":

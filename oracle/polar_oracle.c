@@ -33,7 +33,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "polar_synth.h"
+#include "oracle_synth.h"   /* the oracle's own statement of the workload definition (not the product header) */
 
 typedef struct {
     int n, N, K, crc;
@@ -665,16 +665,12 @@ void orc_get_bler_quick_ref(void *h, const double *ebno, int n_e, const uint8_t 
     free(noise); free(llr); free(prev);
 }
 
-/* ---------- synthetic (counter-based) workload, see include/polar_synth.h ---------- */
+/* ---------- synthetic (counter-based) workload: definition in include/polar_synth.h, restated in oracle_synth.h ---------- */
 /* info bits of trial `trial` (block = trial/100 mirrors the every-100-runs refresh) */
 void orc_synth_info(void *h, uint64_t seed, uint64_t trial, uint8_t *info) {
     orc_t *c = (orc_t *)h;
     uint64_t block = trial / 100;
-    for (int w = 0; w * 128 < c->K; ++w) {
-        uint32_t r[4];
-        polar_synth_info_word(seed, block, (uint32_t)w, r);
-        for (int i = 0; i < 128 && w * 128 + i < c->K; ++i) info[w * 128 + i] = (uint8_t)((r[(i >> 5) & 3] >> (i & 31)) & 1u);
-    }
+    for (int i = 0; i < c->K; ++i) info[i] = (uint8_t)osy_bit(seed, block, OSY_INFO, i);
 }
 /* LLRs of trial `trial` at amplitude s: info -> encode -> BPSK -> +noise -> llr */
 void orc_synth_llr(void *h, uint64_t seed, uint64_t trial, double s, double *llr, uint8_t *info_out) {
@@ -684,9 +680,9 @@ void orc_synth_llr(void *h, uint64_t seed, uint64_t trial, double s, double *llr
     orc_encode(h, info, coded);
     for (int p = 0; p < c->N / 2; ++p) {
         double z0, z1;
-        polar_synth_noise_pair(seed, trial, (uint32_t)p, &z0, &z1);
-        llr[2 * p] = polar_synth_llr(s, coded[2 * p], z0);
-        llr[2 * p + 1] = polar_synth_llr(s, coded[2 * p + 1], z1);
+        osy_noise_pair(seed, trial, (uint32_t)p, &z0, &z1);
+        llr[2 * p] = osy_bpsk_llr(s, coded[2 * p], z0);
+        llr[2 * p + 1] = osy_bpsk_llr(s, coded[2 * p + 1], z1);
     }
     if (info_out) memcpy(info_out, info, (size_t)c->K);
     free(info); free(coded);
@@ -701,15 +697,11 @@ void orc_synth_llr_batch(void *h, uint64_t seed, uint64_t trial0, long B, double
  * y = sym + noise*sigma, fresh info every run (:50). ---------- */
 void orc_synth_bicm_llr(void *h, int cid, uint64_t seed, uint64_t trial, double snr_db, double *llr, uint8_t *info_out) {
     orc_t *c = (orc_t *)h;
-    const int nb = polar_const_nbits(cid);
+    const int nb = osy_nbits(cid);
     uint8_t *info = (uint8_t *)malloc((size_t)c->K), *coded = (uint8_t *)malloc((size_t)c->N);
-    for (int w = 0; w * 128 < c->K; ++w) {          /* block = trial: fresh info bits every run */
-        uint32_t r[4];
-        polar_synth_info_word(seed, trial, (uint32_t)w, r);
-        for (int i = 0; i < 128 && w * 128 + i < c->K; ++i) info[w * 128 + i] = (uint8_t)((r[(i >> 5) & 3] >> (i & 31)) & 1u);
-    }
+    for (int i = 0; i < c->K; ++i) info[i] = (uint8_t)osy_bit(seed, trial, OSY_INFO, i);   /* block = trial: fresh info bits every run */
     orc_encode(h, info, coded);
-    const double norm = polar_const_norm(cid);
+    const double norm = osy_norm(cid);
     const double sigma = sqrt(1.0 / 2) * pow(10.0, -snr_db / 20);
     const double n0 = sigma * sigma;
     const int nsym = c->N / nb;
@@ -717,9 +709,9 @@ void orc_synth_bicm_llr(void *h, int cid, uint64_t seed, uint64_t trial, double 
     for (int i = 0; i < nsym; ++i) {
         int sym = 0;
         for (int j = 0; j < nb; ++j) sym += (1 << j) * coded[i * nb + j];
-        double x = polar_const_point(cid, sym) / norm;
-        double y = x + polar_synth_symbol_noise(seed, trial, (uint32_t)i) * sigma;
-        polar_synth_bicm_demap(cid, norm, y, n0, llr + (size_t)i * nb);
+        double x = osy_point(cid, sym) / norm;
+        double y = x + osy_symbol_noise(seed, trial, (uint32_t)i) * sigma;
+        osy_demap(cid, norm, y, n0, llr + (size_t)i * nb, NULL);
     }
     if (info_out) memcpy(info_out, info, (size_t)c->K);
     free(info); free(coded);
@@ -816,25 +808,21 @@ static void mc_decode_monte_rec(const double *y, const uint8_t *info, int N, dou
 }
 /* one run: fills p1[N] (may be NULL) and adds the per-position error flags to num_err[N] */
 void orc_mc_construction_run(int n, int cid, double design_snr_db, uint64_t seed, uint64_t trial, double *p1_out, uint64_t *num_err) {
-    const int N = 1 << n, nb = polar_const_nbits(cid), nsym = N / nb;
+    const int N = 1 << n, nb = osy_nbits(cid), nsym = N / nb;
     uint8_t *info = (uint8_t *)malloc((size_t)N * 3), *coded = info + N, *ber = coded + N;
     double *p1 = (double *)malloc(sizeof(double) * (size_t)N * 2), *x = p1 + N;
-    for (int w = 0; w * 128 < N; ++w) {
-        uint32_t r[4];
-        polar_synth_mc_info_word(seed, trial, (uint32_t)w, r);
-        for (int i = 0; i < 128 && w * 128 + i < N; ++i) info[w * 128 + i] = (uint8_t)((r[(i >> 5) & 3] >> (i & 31)) & 1u);
-    }
+    for (int i = 0; i < N; ++i) info[i] = (uint8_t)osy_bit(seed, trial, OSY_MCINFO, i);
     mc_encode_rec(info, N, coded);
-    const double norm = polar_const_norm(cid);
+    const double norm = osy_norm(cid);
     const double sigma = sqrt(1.0 / 2) * pow(10.0, -design_snr_db / 20);      /* :170 */
     const double n0 = sigma * sigma;
     for (int i = 0; i < N; ++i) p1[i] = 0.5;                                   /* :176 */
     for (int i = 0; i < nsym; ++i) {
         int sym = 0;
         for (int j = 0; j < nb; ++j) sym += (1 << j) * coded[i * nb + j];
-        double xs = polar_const_point(cid, sym) / norm;
-        double y = xs + sigma * polar_synth_symbol_noise(seed, trial, (uint32_t)i);   /* :171-172 */
-        polar_synth_bicm_demap2(cid, norm, y, n0, NULL, p1 + (size_t)i * nb);         /* :178 */
+        double xs = osy_point(cid, sym) / norm;
+        double y = xs + sigma * osy_symbol_noise(seed, trial, (uint32_t)i);   /* :171-172 */
+        osy_demap(cid, norm, y, n0, NULL, p1 + (size_t)i * nb);               /* :178 */
     }
     mc_decode_monte_rec(p1, info, N, x, ber);
     for (int i = 0; i < N; ++i) num_err[i] += ber[i];

@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "libpolar_amd.so")
 BUILD = os.path.join(HERE, "_build")
 # (source, extra -D, object tag): polar_kernels.hip is compiled twice — LLR-domain and exp-domain kernel families
 SOURCES = [("polar_kernels.hip", ["POLAR_ED_TU=0"], ""), ("polar_kernels.hip", ["POLAR_ED_TU=1"], ".ed"),
-           ("polar_kernels_p1.hip", [], ""), ("polar_channel.hip", [], ""), ("polar_construct.hip", [], ""), ("polar_host.cpp", [], "")]
+           ("polar_kernels_sc.hip", [], ""), ("polar_kernels_p1.hip", [], ""), ("polar_channel.hip", [], ""), ("polar_construct.hip", [], ""), ("polar_host.cpp", [], "")]
 ARCH = "gfx950"
 
 

@@ -149,19 +149,7 @@ __global__ __launch_bounds__(64) void mc_count_compact_kernel(const uint8_t *dec
     }
 }
 
-// float LLRs at the boundary (SURVEY §8b "numeric types at the edge"): widened exactly to the
-// reference's double before the decoder sees them
-__global__ __launch_bounds__(256) void widen_kernel(const float *src, double *dst, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = (double)src[i];
-}
-
 }  // namespace
-
-hipError_t polar_launch_widen(const float *src, double *dst, size_t n, hipStream_t st) {
-    const size_t blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(widen_kernel, dim3((unsigned)(blocks < 16384 ? (blocks ? blocks : 1) : 16384)), dim3(256), 0, st, src, dst, n);
-    return hipGetLastError();
-}
 
 static int grid_for(long B) { return (int)(B < 8192 ? (B > 0 ? B : 1) : 8192); }
 

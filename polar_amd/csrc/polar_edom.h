@@ -1,0 +1,157 @@
+// polar_edom.h — device-side fp64 helpers shared by the decode kernels (gfx950): the table-driven exp / log of the
+// LLR-domain kernel and the exp-domain ("E-form") node arithmetic of the fast kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "polar_device.h"
+
+namespace {
+
+// LDS tables of the fp64 exp / log routines: T[64] = 2^(f/64), RC[129] = 1/(1+j/128), LC[129] = log(1+j/128)
+struct Tabs { const double *T, *RC, *LC; };   // LDS: T[64], RC[129], LC[129]
+
+// NOTE: the Horner starts below are written as a separate multiply and add on purpose. A fused
+// fma(x, c1, c2) has two constant operands, one of which must sit in a VGPR pair; the compiler hoists
+// that pair out of every loop, runs out of registers and RELOADS it from scratch (with a full
+// s_waitcnt vmcnt(0)) inside each f-node. mul-by-constant + add-constant needs no VGPR constant.
+__device__ __forceinline__ double exp_neg(double x, const Tabs &tb) {   // e^-x, x >= 0
+    // -x = k*ln2/64 + s with k = rint(-x*64/ln2) <= 0:  e^-x = 2^(k>>6) * T[k&63] * e^s,  T[f] = 2^(f/64)
+    // (arithmetic shift / two's-complement mask of the NEGATIVE index: no negation, no second table)
+    const double kd = __builtin_rint(x * -92.332482616893657);           // -64/ln2
+    const int k = (int)kd;
+    double s = __builtin_fma(kd, -0.010830424696223417, -x);             // ln2/64, high part (low 16 bits zero)
+    s = __builtin_fma(kd, -2.5728046223276688e-14, s);                   // ln2/64, low part
+    double p = s * (1.0 / 120.0) + 1.0 / 24.0;
+    p = __builtin_fma(p, s, 1.0 / 6.0);
+    p = __builtin_fma(p, s, 0.5);
+    p = __builtin_fma(p, s, 1.0);
+    p = __builtin_fma(p, s, 1.0);
+    return __builtin_ldexp(tb.T[k & 63] * p, k >> 6);
+}
+// table slot of m in [1,2]: m rounded to 7 mantissa bits IS the expansion point c_j = 1 + j/128
+// (integer work on the high word instead of subtract / scale / rint / convert / fma)
+__device__ __forceinline__ int log_slot(double m, double &c) {
+    const int ch = (__double2hiint(m) + 0x1000) & (int)0xFFFFE000;
+    c = __hiloint2double(ch, 0);
+    return (ch - 0x3FF00000) >> 13;                                       // j in [0, 128]
+}
+__device__ __forceinline__ double log_1p2(double m, const Tabs &tb) {    // log(m), m in [1,2]
+    double c;
+    const int j = log_slot(m, c);
+    const double q = (m - c) * tb.RC[j];
+    double p = q * (-1.0 / 6.0) + 0.2;
+    p = __builtin_fma(p, q, -0.25);
+    p = __builtin_fma(p, q, 1.0 / 3.0);
+    p = __builtin_fma(p, q, -0.5);
+    p = __builtin_fma(p, q, 1.0);
+    return __builtin_fma(q, p, tb.LC[j]);
+}
+
+// ================= exp-domain ("E-form") node arithmetic =======================================
+// The LLR-domain f-node needs four transcendentals (two exp + two log1p, ~70 instructions); in the
+// likelihood-ratio domain it is ONE division. A stored value v is
+//     |v| <= 1 :  E-form,  |v| = e^-|x|,  sign(v) = sign(x)          (x = the reference's LLR, |x| < T_E)
+//     |v| >  1 :  L-form,  v = x itself                               (|x| >= T_E = 690: e^-|x| would underflow)
+// so that a relative rounding error of 1.1e-16 in |v| is an ABSOLUTE error of 1.1e-16 in x: the same level
+// of accuracy as the table-driven LLR-domain f-node above (and as the reference's own 1 + e^x), for every
+// magnitude below 690.
+//     f exact (both |x| < 40, PolarCode.cpp:438-441):  E_y = (E_a + E_b) / (1 + E_a E_b),  sign = sa*sb
+//     f min-sum (:442-446):                            the input with the smaller |x|, sign = sa*sb
+//     g (:449-450), signs equal after (1-2u):          E_y = E_a E_b
+//                   signs opposite:                    E_y = min(E_a,E_b) / max(E_a,E_b), sign of the larger |x|
+//     g with an L-form input or an underflowing product (a few % of the wave-steps in the two lowest
+//     layers at 2 dB, none above): the reference's own addition in the LLR domain, with log / exp at the
+//     regime boundary only.
+// The path metric stays in the LLR domain: log(1+e^-|x|) = log1p(E), |x| = -log(E) at the leaves.
+// Decisions within ~1e-10 (relative) of the reference's |x| < 40 test are not taken here: the codeword is
+// flagged and decoded again by the LLR-domain kernel (guard mask, see scl_decode_llr_kernel).
+constexpr double ED_T = 690.0;                       // E-form iff |x| < ED_T
+constexpr double ED_EMIN = 2.3e-300;                 // < e^-690 = 2.26e-300 ... products below this leave the E-form
+constexpr double ED_C40_HI = 4.248354255291589e-18 * (1.0 + 1e-10);   // e^-40 (1 +- 1e-10)
+constexpr double ED_C40_LO = 4.248354255291589e-18 * (1.0 - 1e-10);
+#ifndef ED_NR
+#define ED_NR 1     // v_rcp_f64 is good to 2^-24: one Newton step (2^-48) and the quotient correction (error squared again)
+#endif
+// num / den for normal operands well inside the exponent range: v_rcp_f64 seed, Newton steps on the
+// reciprocal, one correction of the quotient (which squares the remaining error: <= 1 ulp)
+__device__ __forceinline__ double ed_div(double num, double den) {
+    double r = __builtin_amdgcn_rcp(den);
+    double e = __builtin_fma(-den, r, 1.0);
+    r = __builtin_fma(r, e, r);
+#if ED_NR >= 2
+    e = __builtin_fma(-den, r, 1.0);
+    r = __builtin_fma(r, e, r);
+#endif
+    const double q = num * r;
+    const double e2 = __builtin_fma(-den, q, num);
+    return __builtin_fma(e2, r, q);
+}
+__device__ __forceinline__ double ed_with_sign(double r, int signword) {     // r >= 0
+    return __hiloint2double(__double2hiint(r) | (signword & (int)0x80000000), __double2loint(r));
+}
+// f-node. `guard` collects (as a wave mask) the lanes whose |x| < 40 decision is too close to call.
+__device__ __forceinline__ double f_node_e(double a, double b, u64 &guard) {
+    const double fa = fabs(a), fb = fabs(b);
+    const double mx = __builtin_fmax(fa, fb), mn = __builtin_fmin(fa, fb);
+    const double q = ed_div(fa + fb, __builtin_fma(fa, fb, 1.0));
+    const u64 m_hi = __builtin_amdgcn_fcmp(mn, ED_C40_HI, 2);            // mn > e^-40 (1 + 1e-10): certainly |x| < 40
+    const u64 m_lo = __builtin_amdgcn_fcmp(mn, ED_C40_LO, 2);
+    const u64 m_l = __builtin_amdgcn_fcmp(mx, 1.0, 2);                   // an L-form input (rare)
+    guard |= (m_hi ^ m_lo) & ~m_l;
+    // both E-form: exact value, or (min-sum, :442-446) the smaller |x| = the larger E
+    double r = __builtin_amdgcn_inverse_ballot_w64(m_hi) ? q : mx;
+    // one L-form -> the E-form input (mn); both L-form -> the smaller |x| (mn)
+    if (m_l) r = __builtin_amdgcn_inverse_ballot_w64(m_l) ? mn : r;
+    return ed_with_sign(r, __double2hiint(a) ^ __double2hiint(b));
+}
+// general natural logarithm of a positive normal double (tables of log_1p2)
+__device__ __forceinline__ double ed_log(double x, const Tabs &tb) {
+    const int hi = __double2hiint(x);
+    const double e = (double)((hi >> 20) - 1023);
+    const double m = __hiloint2double((hi & 0x000FFFFF) | 0x3FF00000, __double2loint(x));
+    // ln2 split: high part with 32 significant bits (e * hi is exact), low part the rest
+    return __builtin_fma(e, 6.93147180369123816490e-01, __builtin_fma(e, 1.90821492927058770002e-10, log_1p2(m, tb)));
+}
+// |x| of a stored value (E-form: -log E; L-form: itself)
+__device__ __forceinline__ double ed_abs_llr(double v, const Tabs &tb) {
+    const double m = fabs(v);
+    const double l = -ed_log(__builtin_fmin(__builtin_fmax(m, ED_EMIN), 1.0), tb);
+    return (m > 1.0) ? m : l;
+}
+// canonical stored form of an LLR x
+__device__ __forceinline__ double ed_from_llr(double x, const Tabs &tb) {
+    const double fx = fabs(x);
+    const double e = exp_neg(__builtin_fmin(fx, 700.0), tb);
+    return (fx >= ED_T) ? x : ed_with_sign(e, __double2hiint(x));
+}
+// g-node: (1-2u) a + b; `usign` carries u in bit 31 (the other bits are ignored)
+__device__ __forceinline__ double g_node_e(double a, double b, unsigned usign, const Tabs &tb) {
+    const int ha = __double2hiint(a) ^ (int)usign, hb = __double2hiint(b);      // only the sign bits of ha/hb are used
+    const bool same = (int)(ha ^ hb) >= 0;
+    const double p = fabs(a) * fabs(b);
+    const double lo = __builtin_fmin(fabs(a), fabs(b)), hi = __builtin_fmax(fabs(a), fabs(b));
+    const double q = ed_div(lo, hi);                      // == 1.0 exactly when |a| == |b| (b - a = 0)
+    const double r = same ? p : q;
+    int sg = (fabs(a) < fabs(b)) ? ha : hb;               // opposite signs: the larger |x| (smaller E) decides
+    sg = same ? hb : sg;
+    double res = ed_with_sign(r, sg);
+    const u64 m_rare = __builtin_amdgcn_fcmp(hi, 1.0, 2) | __builtin_amdgcn_ballot_w64(same && p < ED_EMIN);
+    if (m_rare) {
+        // reference arithmetic in the LLR domain for the lanes that need it
+        const double xa = ed_with_sign(ed_abs_llr(a, tb), ha), xb = ed_with_sign(ed_abs_llr(b, tb), hb);
+        const double y = xa + xb;
+        const double sl = ed_from_llr(y, tb);
+        if (__builtin_amdgcn_inverse_ballot_w64(m_rare)) res = sl;
+    }
+    return res;
+}
+// channel LLR -> stored form, with the input guard (non-finite, or so small that the reference's f/g
+// results are its own rounding noise)
+__device__ __forceinline__ double ed_from_channel(double x, const Tabs &tb, bool &flag) {
+    const double fx = fabs(x);
+    flag = !(fx < __builtin_inf()) || fx < 1e-9;
+    return ed_from_llr(x, tb);
+}
+
+}  // namespace

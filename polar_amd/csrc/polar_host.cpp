@@ -77,12 +77,14 @@ struct polar_code {
     std::vector<uint32_t> crc_mask;  // [crc*W]
     std::vector<uint8_t> sched;      // [N] rate-0 block schedule for the kernel (0 / 2 / 3)
     std::vector<uint32_t> ctl;       // [N] frozen | sched << 1
+    std::vector<uint32_t> sc_ops;    // schedule of the list-size-1 kernel (PolarScParams::ops)
     // device
     bool dev_ready = false;
     int device = -1, num_cu = 0;
     DevBuf<uint8_t> d_frozen, d_crcm;
     DevBuf<uint16_t> d_order, d_info_rank;
-    DevBuf<uint32_t> d_crc_mask, d_ctl;
+    DevBuf<uint32_t> d_crc_mask, d_ctl, d_sc_ops, d_sc_bits;
+    DevBuf<unsigned int> d_flag_words;
     DevBuf<double> d_llr_scr, d_tabs, d_pre;
     DevBuf<uint32_t> d_c_scr, d_hist_scr;
     // staging for the host-pointer entry points
@@ -148,6 +150,32 @@ int derive_tables(polar_code *h) {
             else ++phi;
         }
     }
+    // schedule of the pruned SC kernel (list size 1): depth-first over the code tree; all-frozen subtrees decide
+    // zeros, all-unfrozen ones decide at their root, a 64-leaf window of partial sums lives in registers
+    h->sc_ops.clear();
+    {
+        auto emit = [&](int type, int S, int base) {
+            int sh = 0; while ((1 << sh) < S) ++sh;
+            h->sc_ops.push_back((uint32_t)type | ((uint32_t)sh << 3) | ((uint32_t)base << 8));
+        };
+        struct Rec {
+            polar_code *h; decltype(emit) &em; int N;
+            void go(int lo, int S) {
+                bool allf = true, nonef = true;
+                for (int i = lo; i < lo + S; ++i) { if (h->frozen[i]) nonef = false; else allf = false; }
+                if (allf) { if (S < N) em(6, S, lo); if (S >= 128) em(2, S, lo); }
+                else if (nonef) em(3, S, lo);
+                else {
+                    const int hS = S / 2;
+                    em(0, hS, lo); go(lo, hS);
+                    em(1, hS, lo); go(lo + hS, hS);
+                    em(4, hS, lo);
+                }
+                if (S == 64 || (S == N && N < 64)) em(5, 1, lo);        // the window [lo, lo + 64) is complete
+            }
+        } rec{h, emit, N};
+        rec.go(0, N);
+    }
     h->ctl.resize(N);
     for (int i = 0; i < N; ++i) h->ctl[i] = (uint32_t)(h->frozen[i] ? 1u : 0u) | ((uint32_t)h->sched[i] << 1);
     // CRC row i as a parity mask over unfrozen ranks, check bit included: crc_check passes iff
@@ -199,6 +227,7 @@ int ensure_device(polar_code *h, DevGuard &dg) {
     int rc;
     if ((rc = upload(h->d_frozen, h->frozen))) return rc;
     if ((rc = upload(h->d_ctl, h->ctl))) return rc;
+    if ((rc = upload(h->d_sc_ops, h->sc_ops))) return rc;
     if ((rc = upload(h->d_order, h->order))) return rc;
     if ((rc = upload(h->d_info_rank, h->info_rank))) return rc;
     if ((rc = upload(h->d_crc_mask, h->crc_mask))) return rc;
@@ -303,6 +332,7 @@ void polar_destroy(polar_code_t *h) {
     h->d_counter.release(); h->d_sel.release(); h->d_work.release();
     h->d_ech.release(); h->d_flags.release(); h->d_list.release(); h->d_count.release();
     h->d_alive[0].release(); h->d_alive[1].release(); h->d_nalive.release(); h->d_mc_ctr.release();
+    h->d_sc_ops.release(); h->d_sc_bits.release(); h->d_flag_words.release();
     delete h;
 }
 
@@ -372,16 +402,16 @@ int polar_decode_scl_llr_batch_dev(polar_code_t *h, const double *d_llr, long B,
     return polar_decode_scl_llr_batch_dev_ev(h, d_llr, B, L, d_out, d_pm, stream, nullptr, nullptr);
 }
 
-static int decode_impl(polar_code_t *h, const double *d_llr, long B, const unsigned int *n_dev, int L, uint8_t *d_out,
+static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, const unsigned int *n_dev, int L, uint8_t *d_out,
                        double *d_pm, void *stream, void *ev_start, void *ev_stop);
 
 int polar_decode_scl_llr_batch_dev_ev(polar_code_t *h, const double *d_llr, long B, int L, uint8_t *d_out,
                                       double *d_pm, void *stream, void *ev_start, void *ev_stop) {
-    return decode_impl(h, d_llr, B, nullptr, L, d_out, d_pm, stream, ev_start, ev_stop);
+    return decode_impl(h, d_llr, 0, B, nullptr, L, d_out, d_pm, stream, ev_start, ev_stop);
 }
 
 // B rows are allocated; when n_dev != nullptr only the first min(B, *n_dev) exist (count read on the device)
-static int decode_impl(polar_code_t *h, const double *d_llr, long B, const unsigned int *n_dev, int L, uint8_t *d_out,
+static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, const unsigned int *n_dev, int L, uint8_t *d_out,
                        double *d_pm, void *stream, void *ev_start, void *ev_stop) {
     if (!h || !d_llr || !d_out) return fail(POLAR_E_ARG, "NULL argument");
     if (L < 1 || L > POLAR_MAX_LIST) return fail(POLAR_E_ARG, "list size %d out of range [1, %d]", L, POLAR_MAX_LIST);
@@ -432,7 +462,7 @@ static int decode_impl(polar_code_t *h, const double *d_llr, long B, const unsig
         p.prefix_q = Q;
         p.prefix_len = Q ? std::min(P, Q) : 0;
     }
-    p.llr = d_llr; p.p0 = nullptr; p.out = d_out; p.pm_out = d_pm;
+    p.llr = (const double *)d_llr; p.llr_f32 = llr_f32; p.p0 = nullptr; p.out = d_out; p.pm_out = d_pm;
     p.frozen = h->d_frozen.p; p.info_rank = h->d_info_rank.p; p.crc_mask = h->d_crc_mask.p; p.tabs = h->d_tabs.p;
     p.ctl = h->d_ctl.p;
     p.pre = nullptr;
@@ -451,6 +481,46 @@ static int decode_impl(polar_code_t *h, const double *d_llr, long B, const unsig
     // device-side work list: no host synchronisation, normally zero entries.
     int mode = h->mode;
     if (const char *e = getenv("POLAR_MODE")) mode = atoi(e);
+    if (L == 1 && mode != 1 && !d_pm) {          // (a requested path metric needs the general kernel: this one has none)
+        // ---- list size 1: pruned successive cancellation, one lane per codeword (polar_kernels_sc.hip); flagged
+        // codewords (degenerate inputs, |x| < 40 decisions too close to call) go through the general kernel below
+        const int wpb_sc = polar_sc_waves_per_block();
+        const long groups64 = (B + 63) / 64;
+        int sgrid = (int)std::min<long>(groups64, (long)h->num_cu * 16);
+        sgrid = ((sgrid + wpb_sc - 1) / wpb_sc) * wpb_sc;
+        const int SLs = polar_sc_lds_layer();
+        const size_t bigs = (h->N > 2 * SLs) ? (size_t)(h->N - 2 * SLs) : 0;
+        const size_t words = (size_t)(h->N + 31) / 32;
+        if ((rc = h->d_ech.ensure((size_t)groups64 * 64 * h->N))) return rc;
+        if ((rc = h->d_flags.ensure((size_t)B))) return rc;
+        if ((rc = h->d_list.ensure((size_t)B))) return rc;
+        if ((rc = h->d_count.ensure(1))) return rc;
+        if ((rc = h->d_flag_words.ensure((size_t)(B + 31) / 32 + 1))) return rc;
+        // (the alpha scratch is shared with the general kernel's, which the fallback pass sizes below)
+        if ((rc = h->d_llr_scr.ensure(std::max((size_t)sgrid * bigs * 64 + 64, (size_t)grid * big * 64 + 64)))) return rc;
+        if ((rc = h->d_sc_bits.ensure((size_t)sgrid * 2 * words * 64 + 64))) return rc;
+        p.llr_scr = h->d_llr_scr.p;
+        HIP_TRY(hipMemsetAsync(h->d_flag_words.p, 0, ((size_t)(B + 31) / 32 + 1) * sizeof(unsigned int), st));
+        HIP_TRY(hipMemsetAsync(h->d_count.p, 0, sizeof(unsigned int), st));
+        HIP_TRY(hipMemsetAsync(p.work, 0, sizeof(unsigned int), st));
+        HIP_TRY(polar_launch_sc_front(d_llr, llr_f32, h->d_ech.p, h->d_flag_words.p, h->d_tabs.p, h->n, B, n_dev, st));
+        PolarScParams sp;
+        sp.n = h->n; sp.N = h->N; sp.K = h->K; sp.B = B;
+        sp.ech_t = h->d_ech.p; sp.out = d_out; sp.ops = h->d_sc_ops.p; sp.n_ops = (int)h->sc_ops.size();
+        sp.order = h->d_order.p; sp.tabs = h->d_tabs.p; sp.a_scr = h->d_llr_scr.p; sp.bits_scr = h->d_sc_bits.p;
+        sp.flag_words = h->d_flag_words.p; sp.work = p.work; sp.n_dev = n_dev;
+        if (ev_start) HIP_TRY(hipEventRecord((hipEvent_t)ev_start, st));
+        HIP_TRY(polar_launch_sc_decode(sp, sgrid, st));
+        if (ev_stop) HIP_TRY(hipEventRecord((hipEvent_t)ev_stop, st));
+        HIP_TRY(polar_launch_sc_flags_expand(h->d_flag_words.p, h->d_flags.p, B, st));
+        HIP_TRY(polar_launch_ed_collect(h->d_flags.p, B, n_dev, h->d_list.p, h->d_count.p, st));
+        HIP_TRY(hipMemsetAsync(p.work, 0, sizeof(unsigned int), st));
+        PolarDecodeParams pf = p;
+        pf.prefix_q = 0; pf.prefix_len = 0; pf.pre = nullptr;
+        pf.cw_list = h->d_list.p; pf.cw_count = h->d_count.p; pf.n_dev = nullptr;
+        HIP_TRY(polar_launch_decode_llr(pf, gs, lds_log, pipe, std::min(grid, 16 * wpb), false, st));
+        return POLAR_OK;
+    }
     const bool ed = (mode == 2) || (mode == 0 && gs >= 8);
     if (ed && gs < 4) return fail(POLAR_E_ARG, "exp-domain mode needs a list size >= 3");
     HIP_TRY(hipMemsetAsync(p.work, 0, sizeof(unsigned int), st));
@@ -466,9 +536,9 @@ static int decode_impl(polar_code_t *h, const double *d_llr, long B, const unsig
     if ((rc = h->d_list.ensure((size_t)B))) return rc;
     if ((rc = h->d_count.ensure(1))) return rc;
     HIP_TRY(hipMemsetAsync(h->d_count.p, 0, sizeof(unsigned int), st));
-    HIP_TRY(polar_launch_ed_front(d_llr, h->d_ech.p, h->d_flags.p, h->d_tabs.p, h->N, B, n_dev, st));
+    HIP_TRY(polar_launch_ed_front(d_llr, llr_f32, h->d_ech.p, h->d_flags.p, h->d_tabs.p, h->N, B, n_dev, st));
     PolarDecodeParams pe = p;
-    pe.llr = h->d_ech.p; pe.flags = h->d_flags.p;
+    pe.llr = h->d_ech.p; pe.llr_f32 = 0; pe.flags = h->d_flags.p;
     if (pe.prefix_q) HIP_TRY(polar_launch_prefix(pe, true, st));
     if (ev_start) HIP_TRY(hipEventRecord((hipEvent_t)ev_start, st));
     HIP_TRY(polar_launch_decode_llr(pe, gs, lds_log, pipe, grid, true, st));
@@ -505,19 +575,11 @@ int polar_decode_scl_llr(polar_code_t *h, const double *llr, int L, uint8_t *out
     return polar_decode_scl_llr_batch(h, llr, 1, L, out);
 }
 
-// single-precision LLRs at the boundary: widened (exactly) to double on the device, then the same path
+// single-precision LLRs at the boundary: every float is widened (exactly) in the load stage of the first kernel that
+// touches the channel values (ed_front_kernel / prefix_kernel / the layer-1 visits) — no staging copy
 int polar_decode_scl_llr_batch_dev_f32(polar_code_t *h, const float *d_llr, long B, int L, uint8_t *d_out,
                                        double *d_pm, void *stream) {
-    if (!h || !d_llr || !d_out) return fail(POLAR_E_ARG, "NULL argument");
-    if (L < 1 || L > POLAR_MAX_LIST) return fail(POLAR_E_ARG, "list size %d out of range [1, %d]", L, POLAR_MAX_LIST);
-    if (B < 0) return fail(POLAR_E_ARG, "negative batch");
-    if (B == 0) return POLAR_OK;
-    DevGuard dg_;
-    int rc = ensure_device(h, dg_);
-    if (rc) return rc;
-    if ((rc = h->d_in.ensure((size_t)B * h->N))) return rc;
-    HIP_TRY(polar_launch_widen(d_llr, h->d_in.p, (size_t)B * h->N, (hipStream_t)stream));
-    return polar_decode_scl_llr_batch_dev(h, h->d_in.p, B, L, d_out, d_pm, stream);
+    return decode_impl(h, d_llr, 1, B, nullptr, L, d_out, d_pm, stream, nullptr, nullptr);
 }
 int polar_decode_scl_llr_batch_f32(polar_code_t *h, const float *llr, long B, int L, uint8_t *out) {
     if (!h || !llr || !out) return fail(POLAR_E_ARG, "NULL argument");
@@ -560,7 +622,7 @@ int polar_decode_scl_p1_batch(polar_code_t *h, const double *p1, const double *p
     PolarDecodeParams p;
     p.n = h->n; p.N = N; p.K = h->K; p.crc = h->crc; p.L = L; p.W = h->W; p.B = B;
     p.prefix_q = 0; p.prefix_len = 0; p.ctl = nullptr; p.pre = nullptr; p.work = nullptr;
-    p.llr = h->d_in.p; p.p0 = h->d_in.p + (size_t)B * N; p.out = h->d_out.p; p.pm_out = nullptr;
+    p.llr = h->d_in.p; p.llr_f32 = 0; p.p0 = h->d_in.p + (size_t)B * N; p.out = h->d_out.p; p.pm_out = nullptr;
     p.frozen = h->d_frozen.p; p.info_rank = h->d_info_rank.p; p.crc_mask = h->d_crc_mask.p; p.tabs = h->d_tabs.p;
     p.llr_scr = h->d_llr_scr.p; p.c_scr = h->d_c_scr.p; p.hist_scr = h->d_hist_scr.p;
     p.flags = nullptr; p.cw_list = nullptr; p.cw_count = nullptr; p.n_dev = nullptr;
@@ -709,7 +771,7 @@ static int mc_round_launch(polar_code_t *h, int constellation, uint64_t seed, ui
             fill_channel(h, p, constellation, ebno[ie]);
             p.llr = h->d_in.p; p.info_out = h->d_bytes_a.p;
             HIP_TRY(polar_launch_synth(p, st));
-            if ((rc = decode_impl(h, h->d_in.p, T, h->d_nalive.p + cur, Ls[li], h->d_out.p, nullptr, st, nullptr, nullptr))) return rc;
+            if ((rc = decode_impl(h, h->d_in.p, 0, T, h->d_nalive.p + cur, Ls[li], h->d_out.p, nullptr, st, nullptr, nullptr))) return rc;
             HIP_TRY(polar_launch_mc_count_compact(h->d_out.p, h->d_bytes_a.p, T, K, h->d_alive[cur].p, h->d_nalive.p + cur,
                                                   h->d_alive[nxt].p, h->d_nalive.p + nxt, h->d_mc_ctr.p + 2 * (size_t)(li * n_e + ie), st));
             cur = nxt;

@@ -9,7 +9,8 @@ struct PolarDecodeParams {
     int W;                       // 32-bit words of decision history = ceil((K+crc)/32)
     int prefix_q, prefix_len;    // all-frozen prefix handled cooperatively: block size Q (0 = off), leaves Pe
     long B;                      // codewords
-    const double *llr;           // [B][N] device (LLR mode: llr; probability mode: p1)
+    const double *llr;           // [B][N] device (LLR mode: llr; probability mode: p1); floats when llr_f32
+    int llr_f32;                 // channel LLRs are float[B][N] (widened in the load)
     const double *p0;            // [B][N] device (probability mode only)
     uint8_t *out;                // [B][K] device
     double *pm_out;              // [B] device or nullptr
@@ -38,7 +39,7 @@ hipError_t polar_launch_prefix_ed1(const PolarDecodeParams &p, hipStream_t st);
 hipError_t polar_launch_decode_llr_ed0(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, hipStream_t st);
 hipError_t polar_launch_decode_llr_ed1(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, hipStream_t st);
 hipError_t polar_launch_decode_llr(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, bool ed, hipStream_t st);
-hipError_t polar_launch_ed_front(const double *llr, double *ech, uint8_t *flags, const double *tabs, int N, long B, const unsigned *n_dev, hipStream_t st);
+hipError_t polar_launch_ed_front(const void *llr, int llr_f32, double *ech, uint8_t *flags, const double *tabs, int N, long B, const unsigned *n_dev, hipStream_t st);
 hipError_t polar_launch_ed_collect(const uint8_t *flags, long B, const unsigned *n_dev, uint32_t *list, unsigned *count, hipStream_t st);
 
 hipError_t polar_launch_decode_p1(const PolarDecodeParams &p, int gs, int grid, hipStream_t st);
@@ -54,6 +55,30 @@ struct PolarScP1Params {
 };
 hipError_t polar_launch_sc_p1(const PolarScP1Params &p, int grid, hipStream_t st);
 
+// list size 1: pruned successive cancellation, one lane per codeword (polar_kernels_sc.hip)
+struct PolarScParams {
+    int n, N, K;
+    long B;
+    const double *ech_t;         // [ceil(B/64)][N][64] device: channel values, stored form, kernel element order (sc_front_kernel)
+    uint8_t *out;                // [B][K] device
+    const uint32_t *ops;         // [n_ops] device: schedule words = type | log2(S) << 3 | first leaf << 8
+    int n_ops;                   //   type 0 F, 1 G, 2 all-frozen (>= 64 leaves), 3 all-unfrozen, 4 combine, 5 flush the 64-leaf window, 6 all-frozen bound
+    const uint16_t *order;       // [N] device (the first K entries are read)
+    const double *tabs;          // [322] device
+    double *a_scr;               // per-wave scratch [grid][N - 16][64]
+    uint32_t *bits_scr;          // per-wave scratch [grid][2][ceil(N/32)][64]
+    unsigned int *flag_words;    // [ceil(B/32)] device, bit = codeword to be decoded again by the general kernel
+    unsigned int *work;          // device counter (zeroed before the launch) or nullptr
+    const unsigned int *n_dev;   // device: only the first min(B, *n_dev) codewords exist, nullptr = B
+};
+size_t polar_sc_lds_bytes();
+int polar_sc_waves_per_block();
+int polar_sc_lds_layer();
+hipError_t polar_launch_sc_front(const void *llr, int llr_f32, double *ech_t, unsigned int *flag_words, const double *tabs,
+                                 int n, long B, const unsigned *n_dev, hipStream_t st);
+hipError_t polar_launch_sc_decode(const PolarScParams &p, int grid_waves, hipStream_t st);
+hipError_t polar_launch_sc_flags_expand(const unsigned int *flag_words, uint8_t *flags, long B, hipStream_t st);
+
 // Monte-Carlo code construction (polar_construct.hip)
 struct PolarConstructParams {
     int n, N;
@@ -67,7 +92,6 @@ struct PolarConstructParams {
     uint8_t *x_scr;              // per-wave scratch [grid][2*N][64]
     unsigned long long *num_err; // [N] device accumulators
 };
-hipError_t polar_launch_widen(const float *src, double *dst, size_t n, hipStream_t st);
 hipError_t polar_launch_mc_front(const PolarConstructParams &p, int grid, hipStream_t st);
 hipError_t polar_launch_mc_genie(const PolarConstructParams &p, int grid, hipStream_t st);
 

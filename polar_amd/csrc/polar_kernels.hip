@@ -29,6 +29,7 @@
 
 #include "polar_kernels.h"
 #include "polar_device.h"
+#include "polar_edom.h"
 
 #ifdef POLAR_PROFILE
 #define PROF_DECL u64 prof_acc[24] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; u64 prof_t = __builtin_readcyclecounter();
@@ -56,44 +57,6 @@ namespace {
 // and the identity  f(a,b) = sgn(a)sgn(b)min(|a|,|b|) + h(|a+b|) - h(|a-b|),  h(x) = log1p(e^-x).
 // Structural exactness is preserved: h(x) == 0 exactly for x >= 36.74 (where the reference's
 // 1+e^-x rounds to 1), f(0,b) == 0 exactly, f is symmetric, log(1+e^x) -> +inf for x > 709.78.
-struct Tabs { const double *T, *RC, *LC; };   // LDS: T[64], RC[129], LC[129]
-
-// NOTE: the Horner starts below are written as a separate multiply and add on purpose. A fused
-// fma(x, c1, c2) has two constant operands, one of which must sit in a VGPR pair; the compiler hoists
-// that pair out of every loop, runs out of registers and RELOADS it from scratch (with a full
-// s_waitcnt vmcnt(0)) inside each f-node. mul-by-constant + add-constant needs no VGPR constant.
-__device__ __forceinline__ double exp_neg(double x, const Tabs &tb) {   // e^-x, x >= 0
-    // -x = k*ln2/64 + s with k = rint(-x*64/ln2) <= 0:  e^-x = 2^(k>>6) * T[k&63] * e^s,  T[f] = 2^(f/64)
-    // (arithmetic shift / two's-complement mask of the NEGATIVE index: no negation, no second table)
-    const double kd = __builtin_rint(x * -92.332482616893657);           // -64/ln2
-    const int k = (int)kd;
-    double s = __builtin_fma(kd, -0.010830424696223417, -x);             // ln2/64, high part (low 16 bits zero)
-    s = __builtin_fma(kd, -2.5728046223276688e-14, s);                   // ln2/64, low part
-    double p = s * (1.0 / 120.0) + 1.0 / 24.0;
-    p = __builtin_fma(p, s, 1.0 / 6.0);
-    p = __builtin_fma(p, s, 0.5);
-    p = __builtin_fma(p, s, 1.0);
-    p = __builtin_fma(p, s, 1.0);
-    return __builtin_ldexp(tb.T[k & 63] * p, k >> 6);
-}
-// table slot of m in [1,2]: m rounded to 7 mantissa bits IS the expansion point c_j = 1 + j/128
-// (integer work on the high word instead of subtract / scale / rint / convert / fma)
-__device__ __forceinline__ int log_slot(double m, double &c) {
-    const int ch = (__double2hiint(m) + 0x1000) & (int)0xFFFFE000;
-    c = __hiloint2double(ch, 0);
-    return (ch - 0x3FF00000) >> 13;                                       // j in [0, 128]
-}
-__device__ __forceinline__ double log_1p2(double m, const Tabs &tb) {    // log(m), m in [1,2]
-    double c;
-    const int j = log_slot(m, c);
-    const double q = (m - c) * tb.RC[j];
-    double p = q * (-1.0 / 6.0) + 0.2;
-    p = __builtin_fma(p, q, -0.25);
-    p = __builtin_fma(p, q, 1.0 / 3.0);
-    p = __builtin_fma(p, q, -0.5);
-    p = __builtin_fma(p, q, 1.0);
-    return __builtin_fma(q, p, tb.LC[j]);
-}
 __device__ __forceinline__ double h_fn(double x, const Tabs &tb) {       // log1p(e^-x), x >= 0
     return log_1p2(1.0 + exp_neg(x, tb), tb);
 }
@@ -207,111 +170,6 @@ __device__ __forceinline__ void softplus_pair(double a, bool skip, const Tabs &t
 }
 
 
-// ================= exp-domain ("E-form") node arithmetic =======================================
-// The LLR-domain f-node needs four transcendentals (two exp + two log1p, ~70 instructions); in the
-// likelihood-ratio domain it is ONE division. A stored value v is
-//     |v| <= 1 :  E-form,  |v| = e^-|x|,  sign(v) = sign(x)          (x = the reference's LLR, |x| < T_E)
-//     |v| >  1 :  L-form,  v = x itself                               (|x| >= T_E = 690: e^-|x| would underflow)
-// so that a relative rounding error of 1.1e-16 in |v| is an ABSOLUTE error of 1.1e-16 in x: the same level
-// of accuracy as the table-driven LLR-domain f-node above (and as the reference's own 1 + e^x), for every
-// magnitude below 690.
-//     f exact (both |x| < 40, PolarCode.cpp:438-441):  E_y = (E_a + E_b) / (1 + E_a E_b),  sign = sa*sb
-//     f min-sum (:442-446):                            the input with the smaller |x|, sign = sa*sb
-//     g (:449-450), signs equal after (1-2u):          E_y = E_a E_b
-//                   signs opposite:                    E_y = min(E_a,E_b) / max(E_a,E_b), sign of the larger |x|
-//     g with an L-form input or an underflowing product (a few % of the wave-steps in the two lowest
-//     layers at 2 dB, none above): the reference's own addition in the LLR domain, with log / exp at the
-//     regime boundary only.
-// The path metric stays in the LLR domain: log(1+e^-|x|) = log1p(E), |x| = -log(E) at the leaves.
-// Decisions within ~1e-10 (relative) of the reference's |x| < 40 test are not taken here: the codeword is
-// flagged and decoded again by the LLR-domain kernel (guard mask, see scl_decode_llr_kernel).
-constexpr double ED_T = 690.0;                       // E-form iff |x| < ED_T
-constexpr double ED_EMIN = 2.3e-300;                 // < e^-690 = 2.26e-300 ... products below this leave the E-form
-constexpr double ED_C40_HI = 4.248354255291589e-18 * (1.0 + 1e-10);   // e^-40 (1 +- 1e-10)
-constexpr double ED_C40_LO = 4.248354255291589e-18 * (1.0 - 1e-10);
-#ifndef ED_NR
-#define ED_NR 1     // v_rcp_f64 is good to 2^-24: one Newton step (2^-48) and the quotient correction (error squared again)
-#endif
-// num / den for normal operands well inside the exponent range: v_rcp_f64 seed, Newton steps on the
-// reciprocal, one correction of the quotient (which squares the remaining error: <= 1 ulp)
-__device__ __forceinline__ double ed_div(double num, double den) {
-    double r = __builtin_amdgcn_rcp(den);
-    double e = __builtin_fma(-den, r, 1.0);
-    r = __builtin_fma(r, e, r);
-#if ED_NR >= 2
-    e = __builtin_fma(-den, r, 1.0);
-    r = __builtin_fma(r, e, r);
-#endif
-    const double q = num * r;
-    const double e2 = __builtin_fma(-den, q, num);
-    return __builtin_fma(e2, r, q);
-}
-__device__ __forceinline__ double ed_with_sign(double r, int signword) {     // r >= 0
-    return __hiloint2double(__double2hiint(r) | (signword & (int)0x80000000), __double2loint(r));
-}
-// f-node. `guard` collects (as a wave mask) the lanes whose |x| < 40 decision is too close to call.
-__device__ __forceinline__ double f_node_e(double a, double b, u64 &guard) {
-    const double fa = fabs(a), fb = fabs(b);
-    const double mx = __builtin_fmax(fa, fb), mn = __builtin_fmin(fa, fb);
-    const double q = ed_div(fa + fb, __builtin_fma(fa, fb, 1.0));
-    const u64 m_hi = __builtin_amdgcn_fcmp(mn, ED_C40_HI, 2);            // mn > e^-40 (1 + 1e-10): certainly |x| < 40
-    const u64 m_lo = __builtin_amdgcn_fcmp(mn, ED_C40_LO, 2);
-    const u64 m_l = __builtin_amdgcn_fcmp(mx, 1.0, 2);                   // an L-form input (rare)
-    guard |= (m_hi ^ m_lo) & ~m_l;
-    // both E-form: exact value, or (min-sum, :442-446) the smaller |x| = the larger E
-    double r = __builtin_amdgcn_inverse_ballot_w64(m_hi) ? q : mx;
-    // one L-form -> the E-form input (mn); both L-form -> the smaller |x| (mn)
-    if (m_l) r = __builtin_amdgcn_inverse_ballot_w64(m_l) ? mn : r;
-    return ed_with_sign(r, __double2hiint(a) ^ __double2hiint(b));
-}
-// general natural logarithm of a positive normal double (tables of log_1p2)
-__device__ __forceinline__ double ed_log(double x, const Tabs &tb) {
-    const int hi = __double2hiint(x);
-    const double e = (double)((hi >> 20) - 1023);
-    const double m = __hiloint2double((hi & 0x000FFFFF) | 0x3FF00000, __double2loint(x));
-    // ln2 split: high part with 32 significant bits (e * hi is exact), low part the rest
-    return __builtin_fma(e, 6.93147180369123816490e-01, __builtin_fma(e, 1.90821492927058770002e-10, log_1p2(m, tb)));
-}
-// |x| of a stored value (E-form: -log E; L-form: itself)
-__device__ __forceinline__ double ed_abs_llr(double v, const Tabs &tb) {
-    const double m = fabs(v);
-    const double l = -ed_log(__builtin_fmin(__builtin_fmax(m, ED_EMIN), 1.0), tb);
-    return (m > 1.0) ? m : l;
-}
-// canonical stored form of an LLR x
-__device__ __forceinline__ double ed_from_llr(double x, const Tabs &tb) {
-    const double fx = fabs(x);
-    const double e = exp_neg(__builtin_fmin(fx, 700.0), tb);
-    return (fx >= ED_T) ? x : ed_with_sign(e, __double2hiint(x));
-}
-// g-node: (1-2u) a + b; `usign` carries u in bit 31 (the other bits are ignored)
-__device__ __forceinline__ double g_node_e(double a, double b, unsigned usign, const Tabs &tb) {
-    const int ha = __double2hiint(a) ^ (int)usign, hb = __double2hiint(b);      // only the sign bits of ha/hb are used
-    const bool same = (int)(ha ^ hb) >= 0;
-    const double p = fabs(a) * fabs(b);
-    const double lo = __builtin_fmin(fabs(a), fabs(b)), hi = __builtin_fmax(fabs(a), fabs(b));
-    const double q = ed_div(lo, hi);                      // == 1.0 exactly when |a| == |b| (b - a = 0)
-    const double r = same ? p : q;
-    int sg = (fabs(a) < fabs(b)) ? ha : hb;               // opposite signs: the larger |x| (smaller E) decides
-    sg = same ? hb : sg;
-    double res = ed_with_sign(r, sg);
-    const u64 m_rare = __builtin_amdgcn_fcmp(hi, 1.0, 2) | __builtin_amdgcn_ballot_w64(same && p < ED_EMIN);
-    if (m_rare) {
-        // reference arithmetic in the LLR domain for the lanes that need it
-        const double xa = ed_with_sign(ed_abs_llr(a, tb), ha), xb = ed_with_sign(ed_abs_llr(b, tb), hb);
-        const double y = xa + xb;
-        const double sl = ed_from_llr(y, tb);
-        if (__builtin_amdgcn_inverse_ballot_w64(m_rare)) res = sl;
-    }
-    return res;
-}
-// channel LLR -> stored form, with the input guard (non-finite, or so small that the reference's f/g
-// results are its own rounding noise)
-__device__ __forceinline__ double ed_from_channel(double x, const Tabs &tb, bool &flag) {
-    const double fx = fabs(x);
-    flag = !(fx < __builtin_inf()) || fx < 1e-9;
-    return ed_from_llr(x, tb);
-}
 // leaf terms for the path metric. LLR-domain kernel: `leaf` is the LLR; E-domain: stored form.
 //   neg  = (llr < 0);  al = |llr|;  sneg = log(1+e^-|llr|);  spos = log(1+e^|llr|)
 template <bool ED>
@@ -341,6 +199,14 @@ __device__ __forceinline__ void leaf_terms(double leaf, bool active, const Tabs 
     }
 }
 }  // namespace
+
+// Channel LLRs at the boundary are doubles (the reference's type) or floats (polar_decode_scl_llr_batch_dev_f32):
+// a float is widened — exactly — in the load itself, there is no staging copy. ch_row() = row `cw` of p.llr.
+__device__ __forceinline__ const double *ch_row(const PolarDecodeParams &p, size_t cw) {
+    return p.llr_f32 ? reinterpret_cast<const double *>(reinterpret_cast<const float *>(p.llr) + cw * (size_t)p.N)
+                     : p.llr + cw * (size_t)p.N;
+}
+#define CH(row, i) (p.llr_f32 ? (double)reinterpret_cast<const float *>(row)[i] : (row)[i])
 
 // Layer storage helpers --------------------------------------------------------------------
 // LDS:    layers with S <= SL; layer of size S starts at element (S-1); element e at [e*64 + lane]
@@ -562,7 +428,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                         const bool in_is_ch = (lam == 1);
                         const bool in_pre = !in_is_ch && p.prefix_q > 0 && 2 * S >= p.prefix_q && phi < 2 * S;
                         // (active lanes are valid ones: codeword g0 + lane / GS)
-                        const double *in0 = in_is_ch ? p.llr + cw_of_lane(lane) * N : nullptr;
+                        const double *in0 = in_is_ch ? ch_row(p, cw_of_lane(lane)) : nullptr;
                         const double *pre_cw = in_pre ? p.pre + cw_of_lane(lane) * (size_t)(N - p.prefix_q + 1) : nullptr;
                         const int pin = (in_is_ch || in_pre) ? 0 : pL.get(sh + 1);
                         const size_t istr = in_pre ? 1 : 64;      // prefix layers are contiguous per codeword
@@ -585,8 +451,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                                     for (int k = 0; k < FU; ++k) {
                                         unsigned i0 = __brev((unsigned)(j + k)) >> (32 - n);
                                         unsigned i1 = __brev((unsigned)(j + k + H)) >> (32 - n);
-                                        a0[k] = in0[i0]; b0[k] = in0[i0 + 1];
-                                        a1[k] = in0[i1]; b1[k] = in0[i1 + 1];
+                                        a0[k] = CH(in0, i0); b0[k] = CH(in0, i0 + 1);
+                                        a1[k] = CH(in0, i1); b1[k] = CH(in0, i1 + 1);
                                     }
                                 } else {
 #pragma unroll
@@ -633,7 +499,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
 #pragma unroll
                                     for (int m = 0; m < 8; ++m) {
                                         const unsigned i0 = __brev((unsigned)(j + m * E)) >> (32 - n);
-                                        a[m] = in0[i0]; b[m] = in0[i0 + 1];
+                                        a[m] = CH(in0, i0); b[m] = CH(in0, i0 + 1);
                                     }
                                 } else {
 #pragma unroll
@@ -745,7 +611,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     size_t istride;
                     const bool in_is_ch = (lam == 1);
                     const bool in_pre = !in_is_ch && p.prefix_q > 0 && 2 * S >= p.prefix_q && phi < 2 * S;
-                    const double *in0 = in_is_ch ? p.llr + cw_of_lane(lane) * N : nullptr;
+                    const double *in0 = in_is_ch ? ch_row(p, cw_of_lane(lane)) : nullptr;
                     const double *pre_cw = in_pre ? p.pre + cw_of_lane(lane) * (size_t)(N - p.prefix_q + 1) : nullptr;
                     constexpr bool in_lds = false;          // (LDS inputs were handled above)
                     istride = 64;
@@ -772,8 +638,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                                 for (int k = 0; k < U; ++k) {
                                     // position j <-> reference beta = bitrev_n(j); (j, j+N/2) <-> (2b', 2b'+1)
                                     unsigned idx = __brev((unsigned)(j + k)) >> (32 - n);
-                                    a[k] = in0[idx];
-                                    b[k] = in0[idx + 1];
+                                    a[k] = CH(in0, idx);
+                                    b[k] = CH(in0, idx + 1);
                                 }
                             } else {
 #pragma unroll
@@ -810,8 +676,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) {
                                     unsigned idx = __brev((unsigned)(j + k)) >> (32 - n);
-                                    a[k] = in0[idx];
-                                    b[k] = in0[idx + 1];
+                                    a[k] = CH(in0, idx);
+                                    b[k] = CH(in0, idx + 1);
                                 }
                             } else {
 #pragma unroll
@@ -836,8 +702,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                             double a, b;
                             if (in_is_ch) {
                                 unsigned idx = __brev((unsigned)j) >> (32 - n);
-                                a = in0[idx];
-                                b = in0[idx + 1];
+                                a = CH(in0, idx);
+                                b = CH(in0, idx + 1);
                             } else {
                                 a = inp[(size_t)j * istride];
                                 b = inp[(size_t)(j + S) * istride];
@@ -1272,7 +1138,7 @@ __global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p) {
     for (long c0 = (long)blockIdx.x * per_block; c0 < Bv; c0 += (long)gridDim.x * per_block) {
         const long cw = c0 + (threadIdx.x >> 5);
         const bool valid = cw < Bv;
-        const double *in0 = p.llr + (size_t)(valid ? cw : 0) * N;
+        const double *in0 = ch_row(p, (size_t)(valid ? cw : 0));
         double *pre = const_cast<double *>(p.pre) + (size_t)(valid ? cw : 0) * (size_t)(N - Q + 1);
         double x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int S = N / 2; S >= Q; S >>= 1) {
@@ -1284,7 +1150,7 @@ __global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p) {
                     double a, b;
                     if (from_ch) {
                         unsigned idx = __brev((unsigned)j) >> (32 - n);
-                        a = in0[idx]; b = in0[idx + 1];
+                        a = CH(in0, idx); b = CH(in0, idx + 1);
                     } else {
                         a = inp[j]; b = inp[j + S];
                     }
@@ -1372,7 +1238,8 @@ hipError_t polar_launch_prefix(const PolarDecodeParams &p, bool ed, hipStream_t 
 // ed_front_kernel — channel LLRs -> stored form of the exp-domain kernel (p.llr -> p.ech), plus the
 // input guard: flags[cw] = 1 when the codeword holds a non-finite LLR or one below 1e-9 (the
 // reference's f-node results are then its own rounding noise), else 0.
-__global__ __launch_bounds__(256) void ed_front_kernel(const double *llr, double *ech, uint8_t *flags, const double *tabs_g, int N, long B, const unsigned *n_dev) {
+template <typename TIN>
+__global__ __launch_bounds__(256) void ed_front_kernel(const TIN *llr, double *ech, uint8_t *flags, const double *tabs_g, int N, long B, const unsigned *n_dev) {
     if (n_dev && (long)*n_dev < B) B = (long)*n_dev;
     __shared__ double tabs[324];
     for (int i = threadIdx.x; i < 322; i += 256) tabs[i] = tabs_g[i];
@@ -1380,22 +1247,23 @@ __global__ __launch_bounds__(256) void ed_front_kernel(const double *llr, double
     const Tabs tb = {tabs, tabs + 64, tabs + 64 + 129};
     const int lane = threadIdx.x & 63;
     for (long cw = (long)blockIdx.x * 4 + (threadIdx.x >> 6); cw < B; cw += (long)gridDim.x * 4) {
-        const double *src = llr + (size_t)cw * N;
+        const TIN *src = llr + (size_t)cw * N;
         double *dst = ech + (size_t)cw * N;
         bool any = false;
         for (int i = lane; i < N; i += 64) {
             bool f;
-            dst[i] = ed_from_channel(src[i], tb, f);
+            dst[i] = ed_from_channel((double)src[i], tb, f);
             any |= f;
         }
         const bool bad = wave_any(any);
         if (lane == 0) flags[cw] = bad ? 1 : 0;
     }
 }
-hipError_t polar_launch_ed_front(const double *llr, double *ech, uint8_t *flags, const double *tabs, int N, long B, const unsigned *n_dev, hipStream_t st) {
+hipError_t polar_launch_ed_front(const void *llr, int llr_f32, double *ech, uint8_t *flags, const double *tabs, int N, long B, const unsigned *n_dev, hipStream_t st) {
     long blocks = (B + 3) / 4;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(ed_front_kernel, dim3((unsigned)blocks), dim3(256), 0, st, llr, ech, flags, tabs, N, B, n_dev);
+    if (llr_f32) hipLaunchKernelGGL(ed_front_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)llr, ech, flags, tabs, N, B, n_dev);
+    else hipLaunchKernelGGL(ed_front_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, st, (const double *)llr, ech, flags, tabs, N, B, n_dev);
     return hipGetLastError();
 }
 // flagged codewords -> work list of the fallback pass (order irrelevant: every codeword is independent)
@@ -1455,8 +1323,8 @@ hipError_t polar_launch_decode_llr_ed1(const PolarDecodeParams &p, int gs, int l
 #else
 hipError_t polar_launch_decode_llr_ed0(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, hipStream_t st) {
     switch (gs) {
-#ifndef POLAR_DEV_GS32
         case 1: return launch_gs<1, false>(p, lds_log, pipe, grid, st);
+#ifndef POLAR_DEV_GS32
         case 2: return launch_gs<2, false>(p, lds_log, pipe, grid, st);
         case 4: return launch_gs<4, false>(p, lds_log, pipe, grid, st);
         case 8: return launch_gs<8, false>(p, lds_log, pipe, grid, st);

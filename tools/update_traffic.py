@@ -20,5 +20,7 @@ if "GRBM_GUI_ACTIVE" in c and "SQ_ACTIVE_INST_VALU" in c:
     cyc = c["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0
     out["shader_clock_ghz_in_profile"] = cyc / d["kernel_time"]["avg_ns"]
     out["valu_busy_frac_in_profile"] = c["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] * 4.0 / (1024.0 * cyc)
+if "SQ_INSTS_VALU" in c:
+    out["valu_insts_per_wave_decode"] = c["SQ_INSTS_VALU"]["mean_per_launch"] / (batch / 2.0)     # L = 32: two codewords per wave
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)
 print(out)
