@@ -125,6 +125,14 @@ __device__ __forceinline__ double ed_from_llr(double x, const Tabs &tb) {
     const double e = exp_neg(__builtin_fmin(fx, 700.0), tb);
     return (fx >= ED_T) ? x : ed_with_sign(e, __double2hiint(x));
 }
+// rare path of the g-node: needed in a few % of the wave-steps of the two lowest layers only
+// (measured: as a real call — noinline — the kernel is 9 % SLOWER: the call ABI costs scratch spills in the callers)
+__device__ __forceinline__ double g_node_e_rare(double a, double b, int ha, int hb, const double *tabs) {
+    const Tabs tb = {tabs, tabs + 64, tabs + 64 + 129};
+    // reference arithmetic in the LLR domain
+    const double xa = ed_with_sign(ed_abs_llr(a, tb), ha), xb = ed_with_sign(ed_abs_llr(b, tb), hb);
+    return ed_from_llr(xa + xb, tb);
+}
 // g-node: (1-2u) a + b; `usign` carries u in bit 31 (the other bits are ignored)
 __device__ __forceinline__ double g_node_e(double a, double b, unsigned usign, const Tabs &tb) {
     const int ha = __double2hiint(a) ^ (int)usign, hb = __double2hiint(b);      // only the sign bits of ha/hb are used
@@ -138,10 +146,7 @@ __device__ __forceinline__ double g_node_e(double a, double b, unsigned usign, c
     double res = ed_with_sign(r, sg);
     const u64 m_rare = __builtin_amdgcn_fcmp(hi, 1.0, 2) | __builtin_amdgcn_ballot_w64(same && p < ED_EMIN);
     if (m_rare) {
-        // reference arithmetic in the LLR domain for the lanes that need it
-        const double xa = ed_with_sign(ed_abs_llr(a, tb), ha), xb = ed_with_sign(ed_abs_llr(b, tb), hb);
-        const double y = xa + xb;
-        const double sl = ed_from_llr(y, tb);
+        const double sl = g_node_e_rare(a, b, ha, hb, tb.T);
         if (__builtin_amdgcn_inverse_ballot_w64(m_rare)) res = sl;
     }
     return res;

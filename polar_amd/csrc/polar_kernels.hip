@@ -489,7 +489,14 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                         // one is a 3-stage f-tree over the eight elements j + m*S/8 of layer lam, so none of the three
                         // intermediate layers is re-read from HBM by the f-visit below it (they are still written:
                         // the later g-visits need them). 16 loads in flight per pass, as the two-layer body.
-                        auto fused4 = [&](const double *inp, double *o0, double *o1, double *o2, double *o3) {
+                        // (measured and dropped: not storing layer 1's second half — the largest array — and re-deriving it
+                        // from the channel values at its only later reader, the g-visit of layer 2 at phi = 3N/4: -9 % HBM
+                        // bytes, but -1.7 % throughput; the re-derivation pass itself is slower than the traffic it saves)
+                        auto fused4 = [&](const double *inp, double *o0, double *o1, double *o2, double *o3, auto NTT) {
+                            // streaming (non-temporal) accesses for the layers of size >= 64 (bit 0: input, 1: o0, 2: o1): they
+                            // are written once and read once or twice much later; the layers of size 16 and 32 stay cacheable
+                            // (measured +1.7 %)
+                            constexpr int NT = decltype(NTT)::value;
                             const int E = S >> 3;
                             uint32_t cw8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                             if (odd && S <= 32) cw8[0] = (uint32_t)(clsmall >> S);
@@ -504,7 +511,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                                 } else {
 #pragma unroll
                                     for (int m = 0; m < 8; ++m) {
-                                        a[m] = inp[(size_t)(j + m * E) * istr]; b[m] = inp[(size_t)(j + m * E + S) * istr];
+                                        if (NT & 1) { a[m] = __builtin_nontemporal_load(inp + (size_t)(j + m * E) * istr); b[m] = __builtin_nontemporal_load(inp + (size_t)(j + m * E + S) * istr); }
+                                        else { a[m] = inp[(size_t)(j + m * E) * istr]; b[m] = inp[(size_t)(j + m * E + S) * istr]; }
                                     }
                                 }
                             };
@@ -522,9 +530,9 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                                 // (issuing the next pass's loads here, ahead of the 15 stores, was measured: -15 % — the
                                 // double-buffered inputs do not fit the 128-VGPR budget)
 #pragma unroll
-                                for (int m = 0; m < 8; ++m) o0[(size_t)(j + m * E) * 64] = v[m];
+                                for (int m = 0; m < 8; ++m) { if (NT & 2) __builtin_nontemporal_store(v[m], o0 + (size_t)(j + m * E) * 64); else o0[(size_t)(j + m * E) * 64] = v[m]; }
 #pragma unroll
-                                for (int m = 0; m < 4; ++m) { v[m] = FN(v[m], v[m + 4]); o1[(size_t)(j + m * E) * 64] = v[m]; }
+                                for (int m = 0; m < 4; ++m) { v[m] = FN(v[m], v[m + 4]); if (NT & 4) __builtin_nontemporal_store(v[m], o1 + (size_t)(j + m * E) * 64); else o1[(size_t)(j + m * E) * 64] = v[m]; }
 #pragma unroll
                                 for (int m = 0; m < 2; ++m) { v[m] = FN(v[m], v[m + 2]); o2[(size_t)(j + m * E) * 64] = v[m]; }
                                 v[0] = FN(v[0], v[1]);
@@ -536,11 +544,17 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
 #define POLAR_LROW(T) (lds_llr + (size_t)((T) - 1) * 64 + lane)
                         if (deep) {
                             const int Q = S / 4, E8 = S / 8;
-                            if (E8 > SL) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_GROW(Q), POLAR_GROW(E8));
-                            else if (Q > SL) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_GROW(Q), POLAR_LROW(E8));
-                            else if (H > SL) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_LROW(Q), POLAR_LROW(E8));
-                            else if (S > SL) fused4(gin, POLAR_GROW(S), POLAR_LROW(H), POLAR_LROW(Q), POLAR_LROW(E8));
-                            else fused4(gin, POLAR_LROW(S), POLAR_LROW(H), POLAR_LROW(Q), POLAR_LROW(E8));
+#ifndef POLAR_NO_NT
+#define POLAR_NTM(x) std::integral_constant<int, (x)>{}
+#else
+#define POLAR_NTM(x) std::integral_constant<int, 0>{}
+#endif
+                            if (E8 > SL) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_GROW(Q), POLAR_GROW(E8), POLAR_NTM(7));      // S >= 128
+                            else if (Q > SL) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_GROW(Q), POLAR_LROW(E8), POLAR_NTM(3));   // S = 64
+                            else if (H > SL) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_LROW(Q), POLAR_LROW(E8), POLAR_NTM(1));   // S = 32: input 64
+                            else if (S > SL) fused4(gin, POLAR_GROW(S), POLAR_LROW(H), POLAR_LROW(Q), POLAR_LROW(E8), POLAR_NTM(0));
+                            else fused4(gin, POLAR_LROW(S), POLAR_LROW(H), POLAR_LROW(Q), POLAR_LROW(E8), POLAR_NTM(0));
+#undef POLAR_NTM
                             pL.set(sh - 2, lig);
                             pL.set(sh - 3, lig);
                         }
@@ -1146,7 +1160,31 @@ __global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p) {
                 const bool from_ch = (2 * S == N);
                 const double *inp = pre + 1 + (size_t)(N - 4 * S);      // layer of size 2S (unused when from_ch)
                 double *outp = pre + 1 + (size_t)(N - 2 * S);
-                for (int j = lig; j < S; j += 32) {
+                // four elements per lane and pass: their eight loads are in flight together (S is a multiple of 128:
+                // S >= Q >= 64 ... the tail loop takes what is left)
+                int j = lig;
+                for (; j + 96 < S; j += 128) {
+                    double a[4], b[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (from_ch) {
+                            const unsigned idx = __brev((unsigned)(j + 32 * k)) >> (32 - n);
+                            a[k] = CH(in0, idx); b[k] = CH(in0, idx + 1);
+                        } else {
+                            a[k] = inp[j + 32 * k]; b[k] = inp[j + 32 * k + S];
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const double r = FN(a[k], b[k]);
+                        outp[j + 32 * k] = r;
+                        if (S == Q) {
+#pragma unroll
+                            for (int rr = 0; rr < 8; ++rr) if (rr == ((j + 32 * k) >> 5)) x[rr] = r;
+                        }
+                    }
+                }
+                for (; j < S; j += 32) {
                     double a, b;
                     if (from_ch) {
                         unsigned idx = __brev((unsigned)j) >> (32 - n);
