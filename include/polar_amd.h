@@ -127,7 +127,7 @@ int polar_count_errors_dev(polar_code_t *h, const uint8_t *d_a, const uint8_t *d
  * Eb/N0 => counted, not simulated", :728-742); the early stop `num_err > max_err` (:725)
  * is evaluated between rounds of `batch` trials (batch = 1 reproduces the reference's per-run granularity).
  * batch = 0 (the default of the host mirrors) picks the rounds itself: max(256, 2 max_err) trials first, then every
- * round as large as all rounds before it together (at most 65536) — a point overshoots the reference's stopping
+ * round as large as all rounds before it together (at most 262144) — a point overshoots the reference's stopping
  * time by less than 2x, and long sweeps still reach full-size launches. Reference defaults: max_runs = 1000,
  * max_err = 100 (:661-662); PolarM: 500 / 50 (PolarCode.m:788-789).
  * A round runs stream-ordered on the device (alive lists compacted there, PolarCode.cpp:728-742); the host reads

@@ -943,10 +943,10 @@ polar_code *clone_on_device(polar_code *h, int dev) {
 }
 
 // round sizes: `batch` fixed, or (batch == 0) geometric — the first round is max(256, 2 max_err) trials, every later
-// one as many as all rounds before it together (at most 65536): the early stop `num_err > max_err` (:725) keeps its
+// one as many as all rounds before it together (at most 262144): the early stop `num_err > max_err` (:725) keeps its
 // meaning (a point overshoots its stopping time by less than 2x) and long sweeps still reach full-size launches
 long next_round(long batch, long max_err, long done, long max_runs) {
-    long T = batch > 0 ? batch : (done == 0 ? std::max<long>(256, 2 * max_err) : std::min<long>(done, 65536));
+    long T = batch > 0 ? batch : (done == 0 ? std::max<long>(256, 2 * max_err) : std::min<long>(done, 262144));
     return std::min(T, max_runs - done);
 }
 

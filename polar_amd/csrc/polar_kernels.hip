@@ -534,7 +534,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
 #pragma unroll
                                 for (int m = 0; m < 4; ++m) { v[m] = FN(v[m], v[m + 4]); if (NT & 4) __builtin_nontemporal_store(v[m], o1 + (size_t)(j + m * E) * 64); else o1[(size_t)(j + m * E) * 64] = v[m]; }
 #pragma unroll
-                                for (int m = 0; m < 2; ++m) { v[m] = FN(v[m], v[m + 2]); o2[(size_t)(j + m * E) * 64] = v[m]; }
+                                for (int m = 0; m < 2; ++m) { v[m] = FN(v[m], v[m + 2]); if (NT & 8) __builtin_nontemporal_store(v[m], o2 + (size_t)(j + m * E) * 64); else o2[(size_t)(j + m * E) * 64] = v[m]; }
                                 v[0] = FN(v[0], v[1]);
                                 o3[(size_t)j * 64] = v[0];
                                 leaf = v[0];            // (the leaf value when S/8 == 1)
@@ -544,7 +544,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
 #define POLAR_LROW(T) (lds_llr + (size_t)((T) - 1) * 64 + lane)
                         if (deep) {
                             const int Q = S / 4, E8 = S / 8;
-#ifndef POLAR_NO_NT
+                            // (also streaming the layer of size 32, so that only the layer of size 16 competes for the L2: -0.5 %)
+#if !defined(POLAR_NO_NT)
 #define POLAR_NTM(x) std::integral_constant<int, (x)>{}
 #else
 #define POLAR_NTM(x) std::integral_constant<int, 0>{}
@@ -552,8 +553,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                             if (E8 > SL) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_GROW(Q), POLAR_GROW(E8), POLAR_NTM(7));      // S >= 128
                             else if (Q > SL) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_GROW(Q), POLAR_LROW(E8), POLAR_NTM(3));   // S = 64
                             else if (H > SL) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_LROW(Q), POLAR_LROW(E8), POLAR_NTM(1));   // S = 32: input 64
-                            else if (S > SL) fused4(gin, POLAR_GROW(S), POLAR_LROW(H), POLAR_LROW(Q), POLAR_LROW(E8), POLAR_NTM(0));
-                            else fused4(gin, POLAR_LROW(S), POLAR_LROW(H), POLAR_LROW(Q), POLAR_LROW(E8), POLAR_NTM(0));
+                            else if (S > SL) fused4(gin, POLAR_GROW(S), POLAR_LROW(H), POLAR_LROW(Q), POLAR_LROW(E8), POLAR_NTM(0));                 // S = 16: input 32
+                            else fused4(gin, POLAR_LROW(S), POLAR_LROW(H), POLAR_LROW(Q), POLAR_LROW(E8), std::integral_constant<int, 0>{});        // S = 8: input 16
 #undef POLAR_NTM
                             pL.set(sh - 2, lig);
                             pL.set(sh - 3, lig);
