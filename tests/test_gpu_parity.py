@@ -255,3 +255,28 @@ def test_more_codewords_than_resident_waves(built_lib, oracle_built, n, K, crc, 
     bad = np.nonzero((want != got).any(axis=1))[0]
     assert bad.size == 0, (bad.size, bad[:8])
     assert (g.decode_scl_llr(llr, L) == got).all()        # and reproducibly so
+
+
+@pytest.mark.parametrize("L", [1, 4, 8, 32])
+def test_degenerate_rows_mixed_with_normal_ones(built_lib, oracle_built, L):
+    """One batch that mixes ordinary noisy codewords with rows the fast kernels must hand to the general kernel
+    (zeros, infinite LLRs of known bits, -inf runs, +-1000 saturated, exact +-1 ties, sub-1e-12 noise, the |llr| = 40 boundary): every row — flagged
+    or not, whichever wave it shares with which neighbour — must equal the oracle's decode of that row."""
+    o, g = _pair(9, 256, 8)
+    N = 512
+    rng = np.random.default_rng(99 + L)
+    llr, _ = o.synth_llr(2024, 0, 384, o.snr_sqrt_linear(1.5))
+    sgn = rng.choice([-1.0, 1.0], (16, N))
+    # "known bits": a noisy codeword with 5 % of its positions at +-inf of the CORRECT sign (infinities of conflicting
+    # sign meet as inf - inf = NaN in the reference's g-node, PolarCode.cpp:449: outside any meaningful domain)
+    coded = o.encode(rng.integers(0, 2, 256).astype(np.uint8)).astype(float)
+    known = (1.0 - 2.0 * coded) * np.where(rng.random(N) < 0.05, np.inf, np.abs(rng.normal(3.0, 1.5, N)) + 0.5)
+    special = [np.zeros(N), 1000.0 * sgn[0], sgn[1], rng.normal(0, 1e-12, N), sgn[2] * rng.choice([0.5, 39.999, 40.0, 40.001, 710.0, 5000.0], N),
+               known, np.where(rng.random(N) < 0.05, -np.inf, 2.0) * np.abs(sgn[4]),
+               np.where(rng.random(N) < 0.1, 0.0, rng.normal(3, 2.5, N)), np.full(N, 2.0), np.full(N, -2.0), 1e80 * sgn[5], 800.0 * sgn[6]]
+    rows = rng.choice(384, len(special), replace=False)
+    for r, s in zip(rows, special):
+        llr[r] = s
+    got = g.decode_scl_llr(llr, L)
+    bad = [int(r) for r in range(384) if (got[r] != o.decode_scl_llr(llr[r], L)).any()]
+    assert not bad, f"rows {bad} differ (special rows: {sorted(int(r) for r in rows)})"
