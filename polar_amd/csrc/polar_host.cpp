@@ -83,7 +83,8 @@ struct polar_code {
     int device = -1, num_cu = 0;
     DevBuf<uint8_t> d_frozen, d_crcm;
     DevBuf<uint16_t> d_order, d_info_rank;
-    DevBuf<uint32_t> d_crc_mask, d_ctl, d_sc_ops, d_sc_bits;
+    DevBuf<uint32_t> d_crc_mask, d_ctl, d_sc_ops, d_sc_bits, d_var_scr;
+    DevBuf<double> d_tab_scr;
     DevBuf<unsigned int> d_flag_words;
     DevBuf<double> d_llr_scr, d_tabs, d_pre;
     DevBuf<uint32_t> d_c_scr, d_hist_scr;
@@ -332,7 +333,7 @@ void polar_destroy(polar_code_t *h) {
     h->d_counter.release(); h->d_sel.release(); h->d_work.release();
     h->d_ech.release(); h->d_flags.release(); h->d_list.release(); h->d_count.release();
     h->d_alive[0].release(); h->d_alive[1].release(); h->d_nalive.release(); h->d_mc_ctr.release();
-    h->d_sc_ops.release(); h->d_sc_bits.release(); h->d_flag_words.release();
+    h->d_sc_ops.release(); h->d_sc_bits.release(); h->d_flag_words.release(); h->d_var_scr.release(); h->d_tab_scr.release();
     delete h;
 }
 
@@ -467,6 +468,7 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
     p.ctl = h->d_ctl.p;
     p.pre = nullptr;
     p.flags = nullptr; p.cw_list = nullptr; p.cw_count = nullptr; p.n_dev = n_dev;
+    p.tab_scr = nullptr; p.var_scr = nullptr;
     if (p.prefix_q) {
         if ((rc = h->d_pre.ensure((size_t)B * (size_t)(h->N - p.prefix_q + 1)))) return rc;
         p.pre = h->d_pre.p;
@@ -539,6 +541,12 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
     HIP_TRY(polar_launch_ed_front(d_llr, llr_f32, h->d_ech.p, h->d_flags.p, h->d_tabs.p, h->N, B, n_dev, st));
     PolarDecodeParams pe = p;
     pe.llr = h->d_ech.p; pe.llr_f32 = 0; pe.flags = h->d_flags.p;
+    if (gs == 32 && !pipe && h->N >= 1024 && p.prefix_q > 0 && !getenv("POLAR_NO_TABLES")) {
+        // table mode: layers 1 and 2 as per-codeword value tables (polar_kernels.hip)
+        if ((rc = h->d_tab_scr.ensure((size_t)grid * G * 3 * h->N + 64))) return rc;
+        if ((rc = h->d_var_scr.ensure((size_t)grid * (h->N / 32) * 64 + 64))) return rc;
+        pe.tab_scr = h->d_tab_scr.p; pe.var_scr = h->d_var_scr.p;
+    }
     if (pe.prefix_q) HIP_TRY(polar_launch_prefix(pe, true, st));
     if (ev_start) HIP_TRY(hipEventRecord((hipEvent_t)ev_start, st));
     HIP_TRY(polar_launch_decode_llr(pe, gs, lds_log, pipe, grid, true, st));
@@ -625,7 +633,7 @@ int polar_decode_scl_p1_batch(polar_code_t *h, const double *p1, const double *p
     p.llr = h->d_in.p; p.llr_f32 = 0; p.p0 = h->d_in.p + (size_t)B * N; p.out = h->d_out.p; p.pm_out = nullptr;
     p.frozen = h->d_frozen.p; p.info_rank = h->d_info_rank.p; p.crc_mask = h->d_crc_mask.p; p.tabs = h->d_tabs.p;
     p.llr_scr = h->d_llr_scr.p; p.c_scr = h->d_c_scr.p; p.hist_scr = h->d_hist_scr.p;
-    p.flags = nullptr; p.cw_list = nullptr; p.cw_count = nullptr; p.n_dev = nullptr;
+    p.flags = nullptr; p.cw_list = nullptr; p.cw_count = nullptr; p.n_dev = nullptr; p.tab_scr = nullptr; p.var_scr = nullptr;
     HIP_TRY(polar_launch_decode_p1(p, gs, grid, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, h->d_out.p, (size_t)B * h->K, hipMemcpyDeviceToHost));

@@ -29,6 +29,8 @@ struct PolarDecodeParams {
     const uint32_t *cw_list;     // work list of codeword indices (fallback pass), nullptr = 0..B-1
     const unsigned int *cw_count;// device: number of entries of cw_list (read by the kernel), nullptr = B
     const unsigned int *n_dev;   // device: only the first min(B, *n_dev) codewords exist (Monte-Carlo alive lists), nullptr = B
+    double *tab_scr;             // table mode (GS = 32, exp-domain): per-wave [grid][2][3N] layer-1/-2 value tables, nullptr = off
+    uint32_t *var_scr;           //   per-wave [grid][N/32][64] variant nibbles of the paths
 };
 
 size_t polar_decode_lds_bytes(int lds_log, int pipe);

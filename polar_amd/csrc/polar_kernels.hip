@@ -278,6 +278,17 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     uint32_t *g_hist = p.hist_scr + (size_t)wave_id * 3 * (size_t)p.W * 64;    // decision words [W][64]
     uint32_t *g_horg = g_hist + (size_t)p.W * 64;                              // link to the previous word's slot
     uint32_t *g_tb = g_horg + (size_t)p.W * 64;                                // winner's words, per-lane copy
+    // ---- table mode (list size 17..32, N >= 1024, exp-domain): layers 1 and 2 are never stored per path.
+    // Every path's layer-1 value x1[e] = g(ch, ch', u1[e]) is one of TWO numbers, its layer-2 value one of 2 / 4 / 8
+    // (phi = N/4: g of the shared first-half layer 1 with u2[j]; phi = N/2: f(x1[j], x1[j+N/4]) -> u1[j], u1[j+N/4];
+    // phi = 3N/4: g(...) -> additionally u2[j]) — the bits being the path's partial sums. The 32 lanes of a codeword
+    // build those values ONCE per codeword (T2[j][variant], 64 B per element: one cache line serves all paths) and each
+    // path keeps 3 bits per element (V words, reached through a slot pointer like every per-path array). The visits of
+    // layer 3 gather their inputs from the table. Two of the seven HBM-resident layers disappear.
+    const int S1 = N / 2, S2 = N / 4;
+    const bool tbl = ED && !PIPE && GS == 32 && N >= 1024 && p.tab_scr != nullptr && p.prefix_q > 0;
+    double *tab_w = tbl ? p.tab_scr + (size_t)wave_id * G * (size_t)(3 * N) : nullptr;       // per codeword: X[N/2][2], T2[N/4][8]
+    uint32_t *g_v = tbl ? p.var_scr + (size_t)wave_id * (size_t)(S2 / 8) * 64 : nullptr;     // V words [N/32][64]
 
     // Work distribution: a wave's first group of codewords is its own index, every further one comes
     // from a device counter. Waves do not take equally long (per-wave time spreads by ~ +-15 %), and with
@@ -409,6 +420,71 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
             const int lam_top = (phi == phi_start && forced_top) ? forced_top : (phi ? (n - __builtin_ctz((unsigned)phi)) : 1);
             double leaf = 0.0;
             for (int lam = lam_top; lam <= lam_stop; ++lam) {
+                if (tbl && lam <= 2 && phi >= S2) {
+                    // phi = N/4, N/2, 3N/4: the visits of layers 1 and 2 are replaced by the table build
+                    const int kind = phi / S2;                      // 1: h (g of the shared layer 1), 2: f, 3: g
+                    LANE_CTX
+                    double *Xc = tab_w + (size_t)(lane / GS) * (size_t)(3 * N), *T2c = Xc + N;
+                    if (valid) {                                    // all lanes of the codeword, whatever their path's state
+                        if (kind == 1) {
+                            const double *x1f = p.pre + cw_of_lane(lane) * (size_t)(N - p.prefix_q + 1) + 1;     // layer 1, first half (prefix kernel)
+                            for (int j = lig; j < S2; j += GS) {
+                                const double a = x1f[j], b = x1f[j + S2];
+                                T2c[8 * j + 0] = g_node_e(a, b, 0u, tb);
+                                T2c[8 * j + 1] = g_node_e(a, b, 0x80000000u, tb);
+                            }
+                        } else {
+                            if (kind == 2) {
+                                const double *chr = ch_row(p, cw_of_lane(lane));
+                                for (int e = lig; e < S1; e += GS) {
+                                    const unsigned i0 = __brev((unsigned)e) >> (32 - n);
+                                    const double a = CH(chr, i0), b = CH(chr, i0 + 1);
+                                    Xc[2 * e + 0] = g_node_e(a, b, 0u, tb);
+                                    Xc[2 * e + 1] = g_node_e(a, b, 0x80000000u, tb);
+                                }
+                                wave_mem_fence();
+                            }
+                            for (int j = lig; j < S2; j += GS) {
+                                const double a0 = Xc[2 * j], a1 = Xc[2 * j + 1], b0 = Xc[2 * (j + S2)], b1 = Xc[2 * (j + S2) + 1];
+                                if (kind == 2) {
+                                    T2c[8 * j + 0] = f_node_e(a0, b0, guard); T2c[8 * j + 1] = f_node_e(a1, b0, guard);
+                                    T2c[8 * j + 2] = f_node_e(a0, b1, guard); T2c[8 * j + 3] = f_node_e(a1, b1, guard);
+                                } else {
+#pragma unroll
+                                    for (int v = 0; v < 8; ++v)
+                                        T2c[8 * j + v] = g_node_e((v & 1) ? a1 : a0, (v & 2) ? b1 : b0, (unsigned)(v >> 2) << 31, tb);
+                                }
+                            }
+                        }
+                    }
+                    // the path's variant nibbles V[e] = u1[e] | u1[e + N/4] << 1 | u2[e] << 2 (kind 1: u2[e] only), 8 per word
+                    // (packing them per consumer pass instead — two words per pass — costs more in the build than the
+                    // visit saves: -5 %)
+                    if (active) {
+                        const uint32_t *c1p = g_cl + (size_t)(S1 / 32 - 2) * 64 + gbase + pC.get(n - 1);
+                        const uint32_t *c2p = g_cl + (size_t)(S2 / 32 - 2) * 64 + gbase + pC.get(n - 2);
+                        auto spread = [](uint32_t x) {               // bit i of the low byte -> bit 4i
+                            uint32_t t = (x | (x << 12)) & 0x000F000Fu;
+                            t = (t | (t << 6)) & 0x03030303u;
+                            return (t | (t << 3)) & 0x11111111u;
+                        };
+                        for (int w32 = 0; w32 < S2 / 32; ++w32) {
+                            const uint32_t ua = (kind >= 2) ? c1p[(size_t)w32 * 64] : 0u, ub = (kind >= 2) ? c1p[(size_t)(w32 + S2 / 32) * 64] : 0u;
+                            const uint32_t uc = (kind != 2) ? c2p[(size_t)w32 * 64] : 0u;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                uint32_t vw;
+                                if (kind == 1) vw = spread((uc >> (8 * q)) & 0xFFu);
+                                else vw = spread((ua >> (8 * q)) & 0xFFu) | (spread((ub >> (8 * q)) & 0xFFu) << 1) | (spread((uc >> (8 * q)) & 0xFFu) << 2);
+                                g_v[(size_t)(4 * w32 + q) * 64 + lane] = vw;
+                            }
+                        }
+                        pC.set(15, lig);                             // slot of this path's V words
+                    }
+                    wave_mem_fence();
+                    lam = 2;
+                    continue;                                        // next: layer 3 with the table as its source
+                }
                 const int sh = n - lam;
                 const int S = 1 << sh;
                 const bool odd = (phi >> sh) & 1;
@@ -492,7 +568,9 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                         // (measured and dropped: not storing layer 1's second half — the largest array — and re-deriving it
                         // from the channel values at its only later reader, the g-visit of layer 2 at phi = 3N/4: -9 % HBM
                         // bytes, but -1.7 % throughput; the re-derivation pass itself is slower than the traffic it saves)
-                        auto fused4 = [&](const double *inp, double *o0, double *o1, double *o2, double *o3, auto NTT) {
+                        const bool tsrc = tbl && lam == 3 && phi >= S2;       // inputs come from the layer-2 table
+                        auto fused4 = [&](const double *inp, double *o0, double *o1, double *o2, double *o3, auto NTT, auto TSS) {
+                            constexpr bool TS = decltype(TSS)::value;
                             // streaming (non-temporal) accesses for the layers of size >= 64 (bit 0: input, 1: o0, 2: o1): they
                             // are written once and read once or twice much later; the layers of size 16 and 32 stay cacheable
                             // (measured +1.7 %)
@@ -501,8 +579,18 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                             uint32_t cw8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                             if (odd && S <= 32) cw8[0] = (uint32_t)(clsmall >> S);
                             double a[8], b[8], v[8];
+                            const double *T2c = TS ? tab_w + (size_t)(lane / GS) * (size_t)(3 * N) + N : nullptr;
+                            const uint32_t *vp = TS ? g_v + gbase + pC.get(15) : nullptr;
                             auto load8 = [&](int j) {
-                                if (in_is_ch) {
+                                if (TS) {
+#pragma unroll
+                                    for (int m = 0; m < 8; ++m) {
+                                        const int e0 = j + m * E, e1 = e0 + S;            // elements of layer 2
+                                        const uint32_t w0 = vp[(size_t)(e0 >> 3) * 64], w1 = vp[(size_t)(e1 >> 3) * 64];
+                                        a[m] = T2c[8 * e0 + ((w0 >> (4 * (e0 & 7))) & 7u)];
+                                        b[m] = T2c[8 * e1 + ((w1 >> (4 * (e1 & 7))) & 7u)];
+                                    }
+                                } else if (in_is_ch) {
 #pragma unroll
                                     for (int m = 0; m < 8; ++m) {
                                         const unsigned i0 = __brev((unsigned)(j + m * E)) >> (32 - n);
@@ -550,11 +638,13 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
 #else
 #define POLAR_NTM(x) std::integral_constant<int, 0>{}
 #endif
-                            if (E8 > SL) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_GROW(Q), POLAR_GROW(E8), POLAR_NTM(7));      // S >= 128
-                            else if (Q > SL) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_GROW(Q), POLAR_LROW(E8), POLAR_NTM(3));   // S = 64
-                            else if (H > SL) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_LROW(Q), POLAR_LROW(E8), POLAR_NTM(1));   // S = 32: input 64
-                            else if (S > SL) fused4(gin, POLAR_GROW(S), POLAR_LROW(H), POLAR_LROW(Q), POLAR_LROW(E8), POLAR_NTM(0));                 // S = 16: input 32
-                            else fused4(gin, POLAR_LROW(S), POLAR_LROW(H), POLAR_LROW(Q), POLAR_LROW(E8), std::integral_constant<int, 0>{});        // S = 8: input 16
+                            typedef std::integral_constant<bool, false> TS0;
+                            if (tsrc) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_GROW(Q), POLAR_GROW(E8), POLAR_NTM(6), std::integral_constant<bool, true>{});
+                            else if (E8 > SL) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_GROW(Q), POLAR_GROW(E8), POLAR_NTM(7), TS0{});      // S >= 128
+                            else if (Q > SL) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_GROW(Q), POLAR_LROW(E8), POLAR_NTM(3), TS0{});   // S = 64
+                            else if (H > SL) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_LROW(Q), POLAR_LROW(E8), POLAR_NTM(1), TS0{});   // S = 32: input 64
+                            else if (S > SL) fused4(gin, POLAR_GROW(S), POLAR_LROW(H), POLAR_LROW(Q), POLAR_LROW(E8), POLAR_NTM(0), TS0{});                 // S = 16: input 32
+                            else fused4(gin, POLAR_LROW(S), POLAR_LROW(H), POLAR_LROW(Q), POLAR_LROW(E8), std::integral_constant<int, 0>{}, TS0{});        // S = 8: input 16
 #undef POLAR_NTM
                             pL.set(sh - 2, lig);
                             pL.set(sh - 3, lig);
