@@ -505,6 +505,17 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
         HIP_TRY(hipMemsetAsync(h->d_flag_words.p, 0, ((size_t)(B + 31) / 32 + 1) * sizeof(unsigned int), st));
         HIP_TRY(hipMemsetAsync(h->d_count.p, 0, sizeof(unsigned int), st));
         HIP_TRY(hipMemsetAsync(p.work, 0, sizeof(unsigned int), st));
+        // two layouts of the same schedule: eight lanes per codeword with the layers <= 256 in LDS (default), or one lane
+        // per codeword (POLAR_SC=1)
+        const char *scv = getenv("POLAR_SC");
+        const bool sc8 = !(scv && atoi(scv) == 1);
+        if (sc8) {
+            const long groups8 = (B + 7) / 8;
+            sgrid = (int)std::min<long>(groups8, (long)h->num_cu * polar_sc8_waves_per_cu(h->N));
+            if ((rc = h->d_llr_scr.ensure(std::max((size_t)sgrid * polar_sc8_scratch_doubles_per_wave(h->N) + 64, (size_t)grid * big * 64 + 64)))) return rc;
+            p.llr_scr = h->d_llr_scr.p;
+            HIP_TRY(polar_launch_sc8_front(d_llr, llr_f32, h->d_ech.p, h->d_flag_words.p, h->d_tabs.p, h->n, B, n_dev, st));
+        } else
         HIP_TRY(polar_launch_sc_front(d_llr, llr_f32, h->d_ech.p, h->d_flag_words.p, h->d_tabs.p, h->n, B, n_dev, st));
         PolarScParams sp;
         sp.n = h->n; sp.N = h->N; sp.K = h->K; sp.B = B;
@@ -512,7 +523,7 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
         sp.order = h->d_order.p; sp.tabs = h->d_tabs.p; sp.a_scr = h->d_llr_scr.p; sp.bits_scr = h->d_sc_bits.p;
         sp.flag_words = h->d_flag_words.p; sp.work = p.work; sp.n_dev = n_dev;
         if (ev_start) HIP_TRY(hipEventRecord((hipEvent_t)ev_start, st));
-        HIP_TRY(polar_launch_sc_decode(sp, sgrid, st));
+        if (sc8) HIP_TRY(polar_launch_sc8_decode(sp, sgrid, st)); else HIP_TRY(polar_launch_sc_decode(sp, sgrid, st));
         if (ev_stop) HIP_TRY(hipEventRecord((hipEvent_t)ev_stop, st));
         HIP_TRY(polar_launch_sc_flags_expand(h->d_flag_words.p, h->d_flags.p, B, st));
         HIP_TRY(polar_launch_ed_collect(h->d_flags.p, B, n_dev, h->d_list.p, h->d_count.p, st));

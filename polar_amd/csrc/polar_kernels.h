@@ -79,6 +79,14 @@ int polar_sc_lds_layer();
 hipError_t polar_launch_sc_front(const void *llr, int llr_f32, double *ech_t, unsigned int *flag_words, const double *tabs,
                                  int n, long B, const unsigned *n_dev, hipStream_t st);
 hipError_t polar_launch_sc_decode(const PolarScParams &p, int grid_waves, hipStream_t st);
+// eight lanes per codeword, layers <= 256 in LDS (same schedule, channel values permuted per codeword [B][N])
+size_t polar_sc8_lds_bytes(int N);
+int polar_sc8_waves_per_block();
+int polar_sc8_waves_per_cu(int N);
+size_t polar_sc8_scratch_doubles_per_wave(int N);
+hipError_t polar_launch_sc8_front(const void *llr, int llr_f32, double *ech_p, unsigned int *flag_words, const double *tabs,
+                                  int n, long B, const unsigned *n_dev, hipStream_t st);
+hipError_t polar_launch_sc8_decode(const PolarScParams &p, int grid_waves, hipStream_t st);
 hipError_t polar_launch_sc_flags_expand(const unsigned int *flag_words, uint8_t *flags, long B, hipStream_t st);
 
 // Monte-Carlo code construction (polar_construct.hip)

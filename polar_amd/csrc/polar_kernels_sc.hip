@@ -284,6 +284,251 @@ __global__ __launch_bounds__(64 * SC_WPB, 4) void sc_decode_kernel(PolarScParams
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// sc8_* — the same schedule with EIGHT LANES PER CODEWORD (8 codewords per wave): element j of a layer lives in
+// sublane j & 7, row j >> 3, so the layers of size <= 256 (511 values per codeword) fit the LDS — 33 KiB per wave —
+// and only the top layers (512, 1024 at N = 2048) stream through HBM; a batch of 65 536 codewords is 8 192 waves
+// instead of 1 024. Nodes of size >= 8 are lane-local (j and j + S share the sublane), the three narrowest layers
+// exchange across sublanes. Partial sums and decisions are 32-bit words [word][codeword] in LDS.
+#ifndef SC8_SL_DEF
+#define SC8_SL_DEF 32
+#endif
+constexpr int SC8_SL = SC8_SL_DEF;             // layers of size <= SC8_SL live in LDS
+#ifndef SC8_U
+#define SC8_U 4
+#endif
+#ifndef SC8_WPB_DEF
+#define SC8_WPB_DEF 4
+#endif
+constexpr int SC8_WPB = SC8_WPB_DEF;           // waves per block (they share the 2.6 KiB of exp/log tables)
+__device__ __forceinline__ int sc8_rowbase(int S) { return S < 8 ? (S == 1 ? 0 : (S == 2 ? 1 : 2)) : (S / 8 + 2); }   // rows: 1,1,1,1,2,4,...
+constexpr int SC8_ROWS = 3 + (2 * SC8_SL / 8 - 1);     // sizes 1, 2, 4 | 8 .. SC8_SL
+
+template <typename TIN>
+__global__ __launch_bounds__(256) void sc8_front_kernel(const TIN *llr, double *ech_p, unsigned int *flag_words, const double *tabs_g,
+                                                        int n, long B, const unsigned *n_dev, int staged) {
+    __shared__ double tabs[324];
+    for (int i = threadIdx.x; i < 322; i += 256) tabs[i] = tabs_g[i];
+    __syncthreads();
+    const Tabs tb = {tabs, tabs + 64, tabs + 64 + 129};
+    if (n_dev && (long)*n_dev < B) B = (long)*n_dev;
+    const int N = 1 << n;
+    extern __shared__ double row[];                  // N doubles when the row fits (staged = 1): both sides coalesced
+    for (long cw = blockIdx.x; cw < B; cw += gridDim.x) {
+        bool any = false;
+        // element e of the kernel's order is channel position bitrev_n(e)
+        for (int i = threadIdx.x; i < N; i += 256) {
+            bool f;
+            const double v = ed_from_channel((double)llr[(size_t)cw * N + i], tb, f);
+            any |= f;
+            if (staged) row[i] = v;
+            else ech_p[(size_t)cw * N + (__brev((unsigned)i) >> (32 - n))] = v;
+        }
+        if (staged) {
+            __syncthreads();
+            for (int e = threadIdx.x; e < N; e += 256) ech_p[(size_t)cw * N + e] = row[__brev((unsigned)e) >> (32 - n)];
+            __syncthreads();
+        }
+        if (any) atomicOr(&flag_words[cw >> 5], 1u << (cw & 31));
+    }
+}
+
+__global__ __launch_bounds__(64 * SC8_WPB) void sc8_decode_kernel(PolarScParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wave_id = blockIdx.x * SC8_WPB + wib;
+    const int nwaves = gridDim.x * SC8_WPB;
+    const int N = p.N, K = p.K;
+    const int sub = lane & 7, cws = lane >> 3;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *tabs = reinterpret_cast<double *>(smem);
+    for (int i = threadIdx.x; i < 322; i += SC8_WPB * 64) tabs[i] = p.tabs[i];
+    __syncthreads();
+    const Tabs tb = {tabs, tabs + 64, tabs + 64 + 129};
+    const int words = (N + 31) / 32;
+    const size_t wave_lds = (size_t)SC8_ROWS * 64 * 8 + (size_t)2 * words * 8 * 4;
+    unsigned char *wb = smem + 324 * 8 + (size_t)wib * wave_lds;
+    double *lds = reinterpret_cast<double *>(wb);                                  // [SC8_ROWS][64]
+    uint32_t *bw = reinterpret_cast<uint32_t *>(wb + (size_t)SC8_ROWS * 64 * 8);   // partial sums [words][8]
+    uint32_t *uw = bw + (size_t)words * 8;                                          // decisions    [words][8]
+    const int big_rows = (N > 2 * SC8_SL) ? (N - 2 * SC8_SL) / 8 : 0;              // rows of the layers 512 .. N/2
+    double *g_a = p.a_scr + (size_t)wave_id * (size_t)big_rows * 64;
+    long Bv = p.B;
+    if (p.n_dev && (long)*p.n_dev < Bv) Bv = (long)*p.n_dev;
+    const long groups = (Bv + 7) / 8;
+    typedef const uint32_t __attribute__((address_space(4))) *kconst_u32;
+    const kconst_u32 ops = (kconst_u32)(uintptr_t)p.ops;
+    u64 guard = 0;
+
+    for (long g = wave_id; g < groups;) {
+        const long cw = g * 8 + cws;
+        const bool valid = cw < Bv;
+        const double *ch = p.ech_t + (size_t)(valid ? cw : 0) * N;               // this codeword's channel values, kernel order
+        for (int i = lane; i < 2 * words * 8; i += 64) bw[i] = 0u;               // (bw and uw are contiguous)
+        guard = 0;
+        wave_mem_fence();
+        for (int io = 0; io < p.n_ops; ++io) {
+            const uint32_t op = ops[io];
+            const int type = (int)(op & 7u), sh = (int)((op >> 3) & 15u), base = (int)(op >> 8);
+            const int S = 1 << sh;
+            if (type <= 1) {
+                if (S >= 8) {
+                    const int R = S / 8;
+                    // source rows r and r + R (element j = 8r + sub and j + S), destination row r
+                    auto visit = [&](const double *src, size_t sstr, double *dst) {
+                        for (int r = 0; r < R; r += SC8_U) {
+                            double a[SC8_U], b[SC8_U];
+#pragma unroll
+                            for (int k = 0; k < SC8_U; ++k) if (r + k < R) { a[k] = src[(size_t)(r + k) * sstr]; b[k] = src[(size_t)(r + k + R) * sstr]; }
+#pragma unroll
+                            for (int k = 0; k < SC8_U; ++k) if (r + k < R) {
+                                double y;
+                                if (type == 0) y = f_node_e(a[k], b[k], guard);
+                                else {
+                                    const int j = base + 8 * (r + k) + sub;
+                                    const uint32_t w = bw[(size_t)(j >> 5) * 8 + cws];
+                                    y = g_node_e(a[k], b[k], w << (31 - (j & 31)), tb);
+                                }
+                                dst[(size_t)(r + k) * 64] = y;
+                            }
+                        }
+                    };
+                    double *dl = lds + (size_t)sc8_rowbase(S) * 64 + lane;
+                    double *dg = g_a + (size_t)((S - 2 * SC8_SL) / 8) * 64 + lane;
+                    if (2 * S == N) {                      // source = channel: 8 consecutive doubles per codeword and row
+                        if (S <= SC8_SL) visit(ch + sub, 8, dl); else visit(ch + sub, 8, dg);
+                    } else if (2 * S <= SC8_SL) visit(lds + (size_t)sc8_rowbase(2 * S) * 64 + lane, 64, dl);
+                    else if (S <= SC8_SL) visit(g_a + (size_t)((2 * S - 2 * SC8_SL) / 8) * 64 + lane, 64, dl);
+                    else visit(g_a + (size_t)((2 * S - 2 * SC8_SL) / 8) * 64 + lane, 64, dg);
+                } else {
+                    // S = 4, 2, 1: the source (size 2S <= 8) is one row; element j + S sits S sublanes to the right
+                    const double v = (2 * S == N) ? ch[sub & (2 * S - 1)] : lds[(size_t)sc8_rowbase(2 * S) * 64 + lane];
+                    const double vb0 = __shfl(v, lane + S, 64);
+                    const double va = (sub < S) ? v : 0.5, vb = (sub < S) ? vb0 : 0.5;      // (idle sublanes: harmless operands)
+                    double y;
+                    if (type == 0) y = f_node_e(va, vb, guard);
+                    else {
+                        const int j = base + sub;
+                        const uint32_t w = bw[(size_t)(j >> 5) * 8 + cws];
+                        y = g_node_e(va, vb, w << (31 - (j & 31)), tb);
+                    }
+                    lds[(size_t)sc8_rowbase(S) * 64 + lane] = y;
+                }
+                wave_mem_fence();
+            } else if (type == 3) {
+                // ---- all-unfrozen subtree: hard decisions of its root (exact zero -> general kernel), their polar transform
+                const double *src = (S == N) ? nullptr : (S <= SC8_SL ? lds + (size_t)sc8_rowbase(S) * 64 + lane
+                                                                      : g_a + (size_t)((S - 2 * SC8_SL) / 8) * 64 + lane);
+                const int R = S >= 8 ? S / 8 : 1;
+                bool zero = false;
+                for (int r4 = 0; r4 < R; r4 += 4) {
+                    uint32_t acc = 0;
+                    for (int k = 0; k < 4 && r4 + k < R; ++k) {
+                        const double v = (S == N) ? ch[(size_t)(r4 + k) * 8 + sub] : src[(size_t)(r4 + k) * 64];
+                        const bool in = (S >= 8) || sub < S;
+                        zero |= in && fabs(v) == 1.0;
+                        const u64 bal = __builtin_amdgcn_ballot_w64(in && ed_is_neg(v));
+                        acc |= (uint32_t)((bal >> (8 * cws)) & 0xFFull) << (8 * k);
+                    }
+                    if (sub == 0) {
+                        const int j0 = base + 8 * r4;
+                        if (S >= 32) bw[(size_t)(j0 >> 5) * 8 + cws] = acc;
+                        else bw[(size_t)(j0 >> 5) * 8 + cws] |= acc << (j0 & 31);
+                    }
+                }
+                guard |= __builtin_amdgcn_ballot_w64(zero);
+                wave_mem_fence();
+                if (sub == 0) {
+                    if (S <= 32) {
+                        const int sft = base & 31;
+                        const uint32_t m = (S == 32) ? 0xFFFFFFFFu : ((1u << S) - 1u);
+                        const uint32_t x = (bw[(size_t)(base >> 5) * 8 + cws] >> sft) & m;
+                        uw[(size_t)(base >> 5) * 8 + cws] |= (uint32_t)bits_transform((u64)x, S) << sft;
+                    } else {
+                        const int nw = S / 32, w0b = base >> 5;
+                        for (int b0 = 0; b0 < nw; ++b0) {
+                            uint32_t x = 0;
+                            for (int b1 = b0; b1 < nw; ++b1) if ((b1 & b0) == b0) x ^= bw[(size_t)(w0b + b1) * 8 + cws];
+                            uw[(size_t)(w0b + b0) * 8 + cws] = (uint32_t)bits_transform((u64)x, 32);
+                        }
+                    }
+                }
+                wave_mem_fence();
+            } else if (type == 4) {
+                // ---- combine: left half ^= right half (child size S)
+                if (S >= 32) {
+                    for (int w = sub; w < S / 32; w += 8)
+                        bw[(size_t)((base >> 5) + w) * 8 + cws] ^= bw[(size_t)(((base + S) >> 5) + w) * 8 + cws];
+                } else if (sub == 0) {
+                    const int sft = base & 31;
+                    uint32_t x = bw[(size_t)(base >> 5) * 8 + cws];
+                    x ^= ((x >> (sft + S)) & ((1u << S) - 1u)) << sft;
+                    bw[(size_t)(base >> 5) * 8 + cws] = x;
+                }
+                wave_mem_fence();
+            } else if (type == 6) {
+                // ---- all-frozen bound (see sc_decode_kernel): sum of |x| over the root <= 690, else general kernel
+                const double *src = S <= SC8_SL ? lds + (size_t)sc8_rowbase(S) * 64 + lane : g_a + (size_t)((S - 2 * SC8_SL) / 8) * 64 + lane;
+                const int R = S >= 8 ? S / 8 : 1;
+                double P = 1.0;
+                bool bad = false;
+                for (int r = 0; r < R; ++r) {
+                    const double m = fabs(src[(size_t)r * 64]);
+                    const bool in = (S >= 8) || sub < S;
+                    bad |= in && m > 1.0;
+                    P *= in ? __builtin_fmin(m, 1.0) : 1.0;
+                    bad |= P < 1e-300;
+                    P = __builtin_fmax(P, 1e-300);
+                }
+#pragma unroll
+                for (int off = 1; off < 8; off <<= 1) {
+                    P *= __shfl_xor(P, off, 64);
+                    bad |= P < 1e-300;
+                    P = __builtin_fmax(P, 1e-300);
+                }
+                guard |= __builtin_amdgcn_ballot_w64(bad);
+            }
+            // (types 2 and 5 — zero fill, window flush — have nothing to do here: the bit arrays start at zero)
+        }
+        wave_mem_fence();
+        if (valid && sub == 0 && ((guard >> (8 * cws)) & 0xFFull)) atomicOr(&p.flag_words[cw >> 5], 1u << (cw & 31));
+        // ---- info bits, one codeword at a time across the wave
+        for (int c = 0; c < 8; ++c) {
+            const long cwc = g * 8 + c;
+            if (cwc >= Bv) break;
+            for (int b = lane; b < K; b += 64) {
+                const unsigned pos = p.order[b];
+                p.out[(size_t)cwc * K + b] = (uint8_t)((uw[(size_t)(pos >> 5) * 8 + c] >> (pos & 31)) & 1u);
+            }
+        }
+        wave_mem_fence();
+        if (p.work) {
+            unsigned nxt = 0;
+            if (lane == 0) nxt = atomicAdd(p.work, 1u);
+            g = (long)nwaves + (long)__builtin_amdgcn_readfirstlane((int)nxt);
+        } else {
+            g += nwaves;
+        }
+    }
+}
+size_t polar_sc8_lds_bytes(int N) { return 324 * 8 + (size_t)SC8_WPB * ((size_t)SC8_ROWS * 64 * 8 + (size_t)2 * ((N + 31) / 32) * 8 * 4); }
+int polar_sc8_waves_per_block() { return SC8_WPB; }
+int polar_sc8_waves_per_cu(int N) { const int w = (int)((160 * 1024) / polar_sc8_lds_bytes(N)) * SC8_WPB; return w > 32 ? 32 : w; }
+size_t polar_sc8_scratch_doubles_per_wave(int N) { return (N > 2 * SC8_SL) ? (size_t)(N - 2 * SC8_SL) / 8 * 64 : 0; }
+hipError_t polar_launch_sc8_front(const void *llr, int llr_f32, double *ech_p, unsigned int *flag_words, const double *tabs,
+                                  int n, long B, const unsigned *n_dev, hipStream_t st) {
+    const unsigned blocks = (unsigned)(B < 65536 ? (B ? B : 1) : 65536);
+    const int staged = (n <= 12) ? 1 : 0;                      // the row (<= 32 KiB) is permuted through LDS
+    const size_t sh = staged ? ((size_t)8 << n) : 0;
+    if (llr_f32) hipLaunchKernelGGL(sc8_front_kernel<float>, dim3(blocks), dim3(256), sh, st, (const float *)llr, ech_p, flag_words, tabs, n, B, n_dev, staged);
+    else hipLaunchKernelGGL(sc8_front_kernel<double>, dim3(blocks), dim3(256), sh, st, (const double *)llr, ech_p, flag_words, tabs, n, B, n_dev, staged);
+    return hipGetLastError();
+}
+hipError_t polar_launch_sc8_decode(const PolarScParams &p, int grid_waves, hipStream_t st) {
+    hipLaunchKernelGGL(sc8_decode_kernel, dim3((grid_waves + SC8_WPB - 1) / SC8_WPB), dim3(64 * SC8_WPB), polar_sc8_lds_bytes(p.N), st, p);
+    return hipGetLastError();
+}
+
 // flag bit words -> byte flags of the fallback list builder (ed_collect_kernel reads bytes)
 __global__ __launch_bounds__(256) void sc_flags_expand_kernel(const unsigned int *flag_words, uint8_t *flags, long B) {
     for (long cw = (long)blockIdx.x * 256 + threadIdx.x; cw < B; cw += (long)gridDim.x * 256)
