@@ -83,7 +83,7 @@ struct polar_code {
     int device = -1, num_cu = 0;
     DevBuf<uint8_t> d_frozen, d_crcm;
     DevBuf<uint16_t> d_order, d_info_rank;
-    DevBuf<uint32_t> d_crc_mask, d_ctl, d_sc_ops, d_sc_bits, d_var_scr;
+    DevBuf<uint32_t> d_crc_mask, d_ctl, d_sc_ops, d_var_scr;
     DevBuf<double> d_tab_scr;
     DevBuf<unsigned int> d_flag_words;
     DevBuf<double> d_llr_scr, d_tabs, d_pre;
@@ -152,7 +152,7 @@ int derive_tables(polar_code *h) {
         }
     }
     // schedule of the pruned SC kernel (list size 1): depth-first over the code tree; all-frozen subtrees decide
-    // zeros, all-unfrozen ones decide at their root, a 64-leaf window of partial sums lives in registers
+    // zeros (only their |x| bound is checked), all-unfrozen ones decide at their root
     h->sc_ops.clear();
     {
         auto emit = [&](int type, int S, int base) {
@@ -164,7 +164,7 @@ int derive_tables(polar_code *h) {
             void go(int lo, int S) {
                 bool allf = true, nonef = true;
                 for (int i = lo; i < lo + S; ++i) { if (h->frozen[i]) nonef = false; else allf = false; }
-                if (allf) { if (S < N) em(6, S, lo); if (S >= 128) em(2, S, lo); }
+                if (allf) { if (S < N) em(6, S, lo); }
                 else if (nonef) em(3, S, lo);
                 else {
                     const int hS = S / 2;
@@ -172,7 +172,6 @@ int derive_tables(polar_code *h) {
                     em(1, hS, lo); go(lo + hS, hS);
                     em(4, hS, lo);
                 }
-                if (S == 64 || (S == N && N < 64)) em(5, 1, lo);        // the window [lo, lo + 64) is complete
             }
         } rec{h, emit, N};
         rec.go(0, N);
@@ -333,7 +332,7 @@ void polar_destroy(polar_code_t *h) {
     h->d_counter.release(); h->d_sel.release(); h->d_work.release();
     h->d_ech.release(); h->d_flags.release(); h->d_list.release(); h->d_count.release();
     h->d_alive[0].release(); h->d_alive[1].release(); h->d_nalive.release(); h->d_mc_ctr.release();
-    h->d_sc_ops.release(); h->d_sc_bits.release(); h->d_flag_words.release(); h->d_var_scr.release(); h->d_tab_scr.release();
+    h->d_sc_ops.release(); h->d_flag_words.release(); h->d_var_scr.release(); h->d_tab_scr.release();
     delete h;
 }
 
@@ -484,46 +483,29 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
     int mode = h->mode;
     if (const char *e = getenv("POLAR_MODE")) mode = atoi(e);
     if (L == 1 && mode != 1 && !d_pm) {          // (a requested path metric needs the general kernel: this one has none)
-        // ---- list size 1: pruned successive cancellation, one lane per codeword (polar_kernels_sc.hip); flagged
+        // ---- list size 1: pruned successive cancellation, eight lanes per codeword (polar_kernels_sc.hip); flagged
         // codewords (degenerate inputs, |x| < 40 decisions too close to call) go through the general kernel below
-        const int wpb_sc = polar_sc_waves_per_block();
-        const long groups64 = (B + 63) / 64;
-        int sgrid = (int)std::min<long>(groups64, (long)h->num_cu * 16);
-        sgrid = ((sgrid + wpb_sc - 1) / wpb_sc) * wpb_sc;
-        const int SLs = polar_sc_lds_layer();
-        const size_t bigs = (h->N > 2 * SLs) ? (size_t)(h->N - 2 * SLs) : 0;
-        const size_t words = (size_t)(h->N + 31) / 32;
-        if ((rc = h->d_ech.ensure((size_t)groups64 * 64 * h->N))) return rc;
+        const long groups8 = (B + 7) / 8;
+        const int sgrid = (int)std::min<long>(groups8, (long)h->num_cu * polar_sc8_waves_per_cu(h->N));
+        if ((rc = h->d_ech.ensure((size_t)B * h->N))) return rc;
         if ((rc = h->d_flags.ensure((size_t)B))) return rc;
         if ((rc = h->d_list.ensure((size_t)B))) return rc;
         if ((rc = h->d_count.ensure(1))) return rc;
         if ((rc = h->d_flag_words.ensure((size_t)(B + 31) / 32 + 1))) return rc;
-        // (the alpha scratch is shared with the general kernel's, which the fallback pass sizes below)
-        if ((rc = h->d_llr_scr.ensure(std::max((size_t)sgrid * bigs * 64 + 64, (size_t)grid * big * 64 + 64)))) return rc;
-        if ((rc = h->d_sc_bits.ensure((size_t)sgrid * 2 * words * 64 + 64))) return rc;
+        // (the alpha scratch is shared with the general kernel's, which the fallback pass uses)
+        if ((rc = h->d_llr_scr.ensure(std::max((size_t)sgrid * polar_sc8_scratch_doubles_per_wave(h->N) + 64, (size_t)grid * big * 64 + 64)))) return rc;
         p.llr_scr = h->d_llr_scr.p;
         HIP_TRY(hipMemsetAsync(h->d_flag_words.p, 0, ((size_t)(B + 31) / 32 + 1) * sizeof(unsigned int), st));
         HIP_TRY(hipMemsetAsync(h->d_count.p, 0, sizeof(unsigned int), st));
         HIP_TRY(hipMemsetAsync(p.work, 0, sizeof(unsigned int), st));
-        // two layouts of the same schedule: eight lanes per codeword with the layers <= 256 in LDS (default), or one lane
-        // per codeword (POLAR_SC=1)
-        const char *scv = getenv("POLAR_SC");
-        const bool sc8 = !(scv && atoi(scv) == 1);
-        if (sc8) {
-            const long groups8 = (B + 7) / 8;
-            sgrid = (int)std::min<long>(groups8, (long)h->num_cu * polar_sc8_waves_per_cu(h->N));
-            if ((rc = h->d_llr_scr.ensure(std::max((size_t)sgrid * polar_sc8_scratch_doubles_per_wave(h->N) + 64, (size_t)grid * big * 64 + 64)))) return rc;
-            p.llr_scr = h->d_llr_scr.p;
-            HIP_TRY(polar_launch_sc8_front(d_llr, llr_f32, h->d_ech.p, h->d_flag_words.p, h->d_tabs.p, h->n, B, n_dev, st));
-        } else
-        HIP_TRY(polar_launch_sc_front(d_llr, llr_f32, h->d_ech.p, h->d_flag_words.p, h->d_tabs.p, h->n, B, n_dev, st));
+        HIP_TRY(polar_launch_sc8_front(d_llr, llr_f32, h->d_ech.p, h->d_flag_words.p, h->d_tabs.p, h->n, B, n_dev, st));
         PolarScParams sp;
         sp.n = h->n; sp.N = h->N; sp.K = h->K; sp.B = B;
         sp.ech_t = h->d_ech.p; sp.out = d_out; sp.ops = h->d_sc_ops.p; sp.n_ops = (int)h->sc_ops.size();
-        sp.order = h->d_order.p; sp.tabs = h->d_tabs.p; sp.a_scr = h->d_llr_scr.p; sp.bits_scr = h->d_sc_bits.p;
+        sp.order = h->d_order.p; sp.tabs = h->d_tabs.p; sp.a_scr = h->d_llr_scr.p;
         sp.flag_words = h->d_flag_words.p; sp.work = p.work; sp.n_dev = n_dev;
         if (ev_start) HIP_TRY(hipEventRecord((hipEvent_t)ev_start, st));
-        if (sc8) HIP_TRY(polar_launch_sc8_decode(sp, sgrid, st)); else HIP_TRY(polar_launch_sc_decode(sp, sgrid, st));
+        HIP_TRY(polar_launch_sc8_decode(sp, sgrid, st));
         if (ev_stop) HIP_TRY(hipEventRecord((hipEvent_t)ev_stop, st));
         HIP_TRY(polar_launch_sc_flags_expand(h->d_flag_words.p, h->d_flags.p, B, st));
         HIP_TRY(polar_launch_ed_collect(h->d_flags.p, B, n_dev, h->d_list.p, h->d_count.p, st));

@@ -57,29 +57,22 @@ struct PolarScP1Params {
 };
 hipError_t polar_launch_sc_p1(const PolarScP1Params &p, int grid, hipStream_t st);
 
-// list size 1: pruned successive cancellation, one lane per codeword (polar_kernels_sc.hip)
+// list size 1: pruned successive cancellation (polar_kernels_sc.hip)
 struct PolarScParams {
     int n, N, K;
     long B;
-    const double *ech_t;         // [ceil(B/64)][N][64] device: channel values, stored form, kernel element order (sc_front_kernel)
+    const double *ech_t;         // [B][N] device: channel values, stored form, kernel element order (sc8_front_kernel)
     uint8_t *out;                // [B][K] device
     const uint32_t *ops;         // [n_ops] device: schedule words = type | log2(S) << 3 | first leaf << 8
-    int n_ops;                   //   type 0 F, 1 G, 2 all-frozen (>= 64 leaves), 3 all-unfrozen, 4 combine, 5 flush the 64-leaf window, 6 all-frozen bound
+    int n_ops;                   //   type 0 F, 1 G, 3 all-unfrozen, 4 combine, 6 all-frozen bound
     const uint16_t *order;       // [N] device (the first K entries are read)
     const double *tabs;          // [322] device
-    double *a_scr;               // per-wave scratch [grid][N - 16][64]
-    uint32_t *bits_scr;          // per-wave scratch [grid][2][ceil(N/32)][64]
+    double *a_scr;               // per-wave scratch: the layers larger than the LDS-resident ones, polar_sc8_scratch_doubles_per_wave()
     unsigned int *flag_words;    // [ceil(B/32)] device, bit = codeword to be decoded again by the general kernel
     unsigned int *work;          // device counter (zeroed before the launch) or nullptr
     const unsigned int *n_dev;   // device: only the first min(B, *n_dev) codewords exist, nullptr = B
 };
-size_t polar_sc_lds_bytes();
-int polar_sc_waves_per_block();
-int polar_sc_lds_layer();
-hipError_t polar_launch_sc_front(const void *llr, int llr_f32, double *ech_t, unsigned int *flag_words, const double *tabs,
-                                 int n, long B, const unsigned *n_dev, hipStream_t st);
-hipError_t polar_launch_sc_decode(const PolarScParams &p, int grid_waves, hipStream_t st);
-// eight lanes per codeword, layers <= 256 in LDS (same schedule, channel values permuted per codeword [B][N])
+// eight lanes per codeword (channel values permuted per codeword [B][N])
 size_t polar_sc8_lds_bytes(int N);
 int polar_sc8_waves_per_block();
 int polar_sc8_waves_per_cu(int N);
