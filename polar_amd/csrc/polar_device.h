@@ -20,6 +20,10 @@ struct P16 {
 };
 
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ double readlane_d(double v, int src) {      // src wave-uniform: result lives in SGPRs
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
 // Lane index recomputed on the spot (2 VALU instructions). Everything derived from the lane index is
 // loop-invariant, and with ~190 live values the register allocator parks such invariants in SCRATCH
 // and reloads them in the middle of every leaf step / layer visit (a memory round trip each, with
@@ -93,6 +97,19 @@ __device__ __forceinline__ void group_max_min_u32(unsigned &a, unsigned &b) {
     if (GS >= 32) POLAR_DPP_STAGE("row_bcast:15 row_mask:0xa bank_mask:0xf")
     if (GS >= 64) POLAR_DPP_STAGE("row_bcast:31 row_mask:0xc bank_mask:0xf")
 #undef POLAR_DPP_STAGE
+}
+// max alone (one chain: two wait states between a VALU write and the DPP read of it)
+template <int GS>
+__device__ __forceinline__ void group_max_u32(unsigned &a) {
+#define POLAR_DPP_STAGE(CTRL) asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 " CTRL : "+v"(a));
+    if (GS >= 2) POLAR_DPP_STAGE("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+    if (GS >= 4) POLAR_DPP_STAGE("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+    if (GS >= 8) POLAR_DPP_STAGE("row_half_mirror row_mask:0xf bank_mask:0xf")
+    if (GS >= 16) POLAR_DPP_STAGE("row_mirror row_mask:0xf bank_mask:0xf")
+    if (GS >= 32) POLAR_DPP_STAGE("row_bcast:15 row_mask:0xa bank_mask:0xf")
+    if (GS >= 64) POLAR_DPP_STAGE("row_bcast:31 row_mask:0xc bank_mask:0xf")
+#undef POLAR_DPP_STAGE
+    asm volatile("s_nop 0");
 }
 template <int GS>
 __device__ __forceinline__ constexpr u64 group_result_rows() {

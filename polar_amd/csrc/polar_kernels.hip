@@ -971,63 +971,133 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     const double mb = goodbit ? -pf0 : -pf1;
                     const bool cbad = active && full && !(bl > gmax);
                     const u64 cbm = __ballot(cbad);
-                    sortbuf[lane] = mg;
-                    wave_mem_fence();
-                    int rg = 0, rb = 0;
-                    const double *sb = sortbuf + gbase;
-                    // good fork of path i (index 2i + bit) vs my forks (indices 2*lig + ...): it precedes them
-                    // on a tie exactly when i < lig (for i == lig see below), so the tie-break folds into the
-                    // choice between "<=" and "<"; comparisons produce wave masks, combined on the scalar unit
+                    bool sg, sbd;
+                    if constexpr (GS == 32) {
+                        // Two groups of 32 lanes. (1) Every competitive bad fork is ranked on the SCALAR unit: its metric
+                        // is read into SGPRs, four wave-wide compares give the masks of the good / competitive bad forks
+                        // ordered before it (metric, then fork index 2*path + bit), a population count gives its rank.
+                        // (2) The list stays at L, so k surviving bad forks displace the k WORST good forks of the
+                        // group; those are peeled off by a DPP maximum over the metrics' high words (non-negative
+                        // doubles order like their bit patterns), all lanes sharing the maximal high word at once
+                        // when k allows, otherwise the low words and lane numbers decide, on the scalar unit.
+                        const u64 actm64 = __ballot(active);
+                        const u64 gbm = __ballot(goodbit);
+                        u64 surv = 0;
+                        PROF_CNT(10, 1)
+                        PROF_CNT(11, __popcll(cbm))
+                        for (u64 mi = cbm; mi; mi &= mi - 1) {
+                            const int l_ = __builtin_ctzll(mi);
+                            const double s_mb = readlane_d(mb, l_);
+                            const u64 grp = 0xFFFFFFFFull << (l_ & 32);
+                            const u64 blw = ((1ull << l_) - 1ull) & grp;              // paths below l_ in its group
+                            const u64 self_first = ~gbm & (1ull << l_);              // own good fork is bit 0: lower index
+                            const u64 lt_g = __builtin_amdgcn_fcmp(mg, s_mb, 4), eq_g = __builtin_amdgcn_fcmp(mg, s_mb, 1);
+                            const u64 lt_b = __builtin_amdgcn_fcmp(mb, s_mb, 4), eq_b = __builtin_amdgcn_fcmp(mb, s_mb, 1);
+                            const int r = __popcll((lt_g | (eq_g & (blw | self_first))) & grp & actm64) +
+                                          __popcll((lt_b | (eq_b & blw)) & grp & cbm);
+                            if (r < L) surv |= 1ull << l_;
+                        }
+                        PROF(18)
+                        int k0 = __popcll(surv & 0xFFFFFFFFull), k1 = __popcll(surv >> 32);
+                        u64 alive = actm64;
+                        const unsigned khi = (unsigned)__double2hiint(mg) + 1u, klo = (unsigned)__double2loint(mg);
+                        auto peel = [&](u64 e, int &k) {
+                            const int ne = __popcll(e);
+                            if (ne == 0) { k = 0; return; }
+                            if (ne <= k) { alive &= ~e; k -= ne; return; }
+                            for (; k > 0; --k) {                                       // equal high words: low word, then lane
+                                int best = -1; unsigned blo = 0;
+                                for (u64 q = e; q; q &= q - 1) {
+                                    const int l_ = __builtin_ctzll(q);
+                                    const unsigned lo_ = (unsigned)__builtin_amdgcn_readlane((int)klo, l_);
+                                    if (best < 0 || lo_ >= blo) { best = l_; blo = lo_; }
+                                }
+                                e &= ~(1ull << best);
+                                alive &= ~(1ull << best);
+                            }
+                        };
+                        while (k0 | k1) {
+                            const unsigned h0 = __builtin_amdgcn_inverse_ballot_w64(alive) ? khi : 0u;
+                            unsigned h = h0;
+                            group_max_u32<GS>(h);
+                            const unsigned m0 = (unsigned)__builtin_amdgcn_readlane((int)h, 31), m1 = (unsigned)__builtin_amdgcn_readlane((int)h, 63);
+                            const u64 eq = __ballot(h0 == (lane < 32 ? m0 : m1)) & alive;
+                            if (k0) peel(eq & 0xFFFFFFFFull, k0);
+                            if (k1) peel(eq & 0xFFFFFFFF00000000ull, k1);
+                        }
+                        sg = __builtin_amdgcn_inverse_ballot_w64(alive);
+                        sbd = __builtin_amdgcn_inverse_ballot_w64(surv);
+                        PROF_CNT(13, (__popcll(surv & 0xFFFFFFFFull) > __popcll(surv >> 32)) ? __popcll(surv & 0xFFFFFFFFull) : __popcll(surv >> 32))
+                        PROF(19)
+                    } else {
+                        sortbuf[lane] = mg;
+                        wave_mem_fence();
+                        int rg = 0, rb = 0;
+                        const double *sb = sortbuf + gbase;
+                        // good fork of path i (index 2i + bit) vs my forks (indices 2*lig + ...): it precedes them
+                        // on a tie exactly when i < lig (for i == lig see below), so the tie-break folds into the
+                        // choice between "<=" and "<"; comparisons produce wave masks, combined on the scalar unit
 #pragma unroll 8
-                    for (int i = 0; i < GS; ++i) {
-                        const double v = sb[i];
-                        const u64 below_me = __ballot(lig > i);                    // lanes for which i < lig
-                        const u64 lt_g = __builtin_amdgcn_fcmp(v, mg, 4), le_g = __builtin_amdgcn_fcmp(v, mg, 5);
-                        const u64 lt_b = __builtin_amdgcn_fcmp(v, mb, 4), le_b = __builtin_amdgcn_fcmp(v, mb, 5);
-                        rg += (int)__builtin_amdgcn_inverse_ballot_w64((le_g & below_me) | (lt_g & ~below_me));
-                        rb += (int)__builtin_amdgcn_inverse_ballot_w64((le_b & below_me) | (lt_b & ~below_me));
-                    }
-                    // i == lig: my own good fork is never counted against itself (v < mg is false); against my
-                    // bad fork the strict part (mg < mb) was counted above, a tie goes to the lower fork index
-                    rb += (mg == mb && !goodbit) ? 1 : 0;
-                    PROF(18)
-                    // competitive bad forks (few at low SNR, up to all L when garbage paths fill the list):
-                    // same scheme from the second half of the exchange buffer, iterations without a
-                    // competitive bad fork in any group are skipped on the scalar unit
-                    sortbuf[64 + lane] = mb;
-                    wave_mem_fence();
-                    const double *sbb = sortbuf + 64 + gbase;
-                    u64 any_i = 0;                                       // bit i: some group has a competitive bad fork i
+                        for (int i = 0; i < GS; ++i) {
+                            const double v = sb[i];
+                            const u64 below_me = __ballot(lig > i);                    // lanes for which i < lig
+                            const u64 lt_g = __builtin_amdgcn_fcmp(v, mg, 4), le_g = __builtin_amdgcn_fcmp(v, mg, 5);
+                            const u64 lt_b = __builtin_amdgcn_fcmp(v, mb, 4), le_b = __builtin_amdgcn_fcmp(v, mb, 5);
+                            rg += (int)__builtin_amdgcn_inverse_ballot_w64((le_g & below_me) | (lt_g & ~below_me));
+                            rb += (int)__builtin_amdgcn_inverse_ballot_w64((le_b & below_me) | (lt_b & ~below_me));
+                        }
+                        // i == lig: my own good fork is never counted against itself (v < mg is false); against my
+                        // bad fork the strict part (mg < mb) was counted above, a tie goes to the lower fork index
+                        rb += (mg == mb && !goodbit) ? 1 : 0;
+                        PROF(18)
+                        // competitive bad forks (few at low SNR, up to all L when garbage paths fill the list):
+                        // same scheme from the second half of the exchange buffer, iterations without a
+                        // competitive bad fork in any group are skipped on the scalar unit
+                        sortbuf[64 + lane] = mb;
+                        wave_mem_fence();
+                        const double *sbb = sortbuf + 64 + gbase;
+                        u64 any_i = 0;                                       // bit i: some group has a competitive bad fork i
 #pragma unroll
-                    for (int g = 0; g < 64 / GS; ++g) any_i |= (cbm >> (g * GS)) & gmask;
-                    PROF_CNT(10, 1)
-                    PROF_CNT(11, __popcll(any_i))
+                        for (int g = 0; g < 64 / GS; ++g) any_i |= (cbm >> (g * GS)) & gmask;
+                        PROF_CNT(10, 1)
+                        PROF_CNT(11, __popcll(any_i))
 #ifdef POLAR_PROFILE
-                    {   // statistics only: good forks that some bad fork of their group could displace
-                        const double bmin_true = group_reduce<GS, false>(active ? mb : __builtin_inf(), lane);
-                        const u64 cgm = __ballot(active && !(mg < bmin_true));
-                        u64 any_g = 0;
-                        for (int g = 0; g < 64 / GS; ++g) any_g |= (cgm >> (g * GS)) & gmask;
-                        PROF_CNT(12, __popcll(any_g))
-                    }
+                        {   // statistics only: good forks that some bad fork of their group could displace
+                            const double bmin_true = group_reduce<GS, false>(active ? mb : __builtin_inf(), lane);
+                            const u64 cgm = __ballot(active && !(mg < bmin_true));
+                            u64 any_g = 0;
+                            for (int g = 0; g < 64 / GS; ++g) any_g |= (cgm >> (g * GS)) & gmask;
+                            PROF_CNT(12, __popcll(any_g))
+                        }
 #endif
-                    for (u64 mi = any_i; mi; mi &= mi - 1) {
-                        const int i = __builtin_ctzll(mi);
-                        const double v = sbb[i];
-                        const u64 mine = __ballot(((cbm >> gbase) >> i) & 1ull);      // lanes whose group's bad fork i competes
-                        const u64 below_me = __ballot(lig > i);
-                        const u64 lt_g = __builtin_amdgcn_fcmp(v, mg, 4), le_g = __builtin_amdgcn_fcmp(v, mg, 5);
-                        const u64 lt_b = __builtin_amdgcn_fcmp(v, mb, 4), le_b = __builtin_amdgcn_fcmp(v, mb, 5);
-                        rg += (int)__builtin_amdgcn_inverse_ballot_w64(((le_g & below_me) | (lt_g & ~below_me)) & mine);
-                        rb += (int)__builtin_amdgcn_inverse_ballot_w64(((le_b & below_me) | (lt_b & ~below_me)) & mine);
+                        for (u64 mi = any_i; mi; mi &= mi - 1) {
+                            const int i = __builtin_ctzll(mi);
+                            const double v = sbb[i];
+                            const u64 mine = __ballot(((cbm >> gbase) >> i) & 1ull);      // lanes whose group's bad fork i competes
+                            const u64 below_me = __ballot(lig > i);
+                            const u64 lt_g = __builtin_amdgcn_fcmp(v, mg, 4), le_g = __builtin_amdgcn_fcmp(v, mg, 5);
+                            const u64 lt_b = __builtin_amdgcn_fcmp(v, mb, 4), le_b = __builtin_amdgcn_fcmp(v, mb, 5);
+                            rg += (int)__builtin_amdgcn_inverse_ballot_w64(((le_g & below_me) | (lt_g & ~below_me)) & mine);
+                            rb += (int)__builtin_amdgcn_inverse_ballot_w64(((le_b & below_me) | (lt_b & ~below_me)) & mine);
+                        }
+                        // i == lig: my own bad fork against my good fork: mb < mg cannot hold, a tie goes to the
+                        // lower fork index (the bad fork has the lower index when the good bit is 1)
+                        rg += (cbad && mg == mb && goodbit) ? 1 : 0;
+                        PROF(19)
+#ifdef POLAR_PROFILE
+                        {   // statistics only: surviving bad forks (= killed good forks) per group, max over the groups
+                            const u64 sbm = __ballot(cbad && rb < L);
+                            int kmax = 0, ktot = 0;
+                            for (int g = 0; g < 64 / GS; ++g) { const int k_ = __popcll((sbm >> (g * GS)) & gmask); kmax = k_ > kmax ? k_ : kmax; ktot += k_; }
+                            PROF_CNT(13, kmax)
+                            PROF_CNT(14, kmax <= 4 ? 1 : 0)
+                            PROF_CNT(15, kmax == 0 ? 1 : 0)
+                        }
+#endif
+                        sg = active && (rg < L);
+                        sbd = cbad && (rb < L);
                     }
-                    // i == lig: my own bad fork against my good fork: mb < mg cannot hold, a tie goes to the
-                    // lower fork index (the bad fork has the lower index when the good bit is 1)
-                    rg += (cbad && mg == mb && goodbit) ? 1 : 0;
-                    PROF(19)
                     if (full) {
-                        const bool sg = active && (rg < L);
-                        const bool sbd = cbad && (rb < L);
                         c0 = goodbit ? sbd : sg;
                         c1 = goodbit ? sg : sbd;
                     }

@@ -49,3 +49,4 @@ if a[8] > 0:
     print(f"  unfrozen steps (per wave) {a[8]:.0f}: fast path {100*a[9]/a[8]:.1f}%, full-list ranking {100*a[10]/a[8]:.1f}%")
     if a[10] > 0:
         print(f"  per ranking step: competitive bad forks (union over groups) {a[11]/a[10]:.2f}, contested good forks {a[12]/a[10]:.2f}")
+        print(f"  per ranking step: surviving bad forks (max over groups) {a[13]/a[10]:.2f}; steps with <= 4: {100*a[14]/a[10]:.1f}%, with none: {100*a[15]/a[10]:.1f}%")
