@@ -59,6 +59,20 @@ def test_odd_list_sizes_match_oracle(built_lib, oracle_built, L):
     assert (o.decode_scl_llr(llr, L) == g.decode_scl_llr(llr, L)).all()
 
 
+@pytest.mark.parametrize("L", [17, 24, 31])
+def test_list_sizes_17_to_31_on_the_headline_code(built_lib, oracle_built, L):
+    """Lists of 17..31 paths run in groups of 32 lanes with idle lanes: table mode (N >= 1024) and the scalar-unit fork
+    ranking see a list that is "full" below 32. Noisy rows, plus all-zero and +-1 rows (every metric ties)."""
+    o, g = _pair(11, 1024, 16)
+    llr, _ = o.synth_llr(2718, 0, 160, o.snr_sqrt_linear(1.5))
+    llr[7] = 0.0
+    llr[8] = np.where(np.arange(2048) % 3 == 0, 1.0, -1.0)
+    want = o.decode_scl_llr(llr, L)
+    got = g.decode_scl_llr(llr, L)
+    bad = np.nonzero((want != got).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size}/160 codewords differ (first {bad[:5]}) L={L}"
+
+
 def test_ragged_batches_and_empty(built_lib, oracle_built):
     o, g = _pair(8, 128, 4)
     llr, _ = o.synth_llr(9, 0, 131, o.snr_sqrt_linear(1.5))
