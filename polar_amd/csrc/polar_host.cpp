@@ -175,6 +175,25 @@ int derive_tables(polar_code *h) {
             }
         } rec{h, emit, N};
         rec.go(0, N);
+        // An F or G step followed by the F step of the child it just produced (depth-first order: always the next
+        // entry, one size down) takes that F - and one more - along while its results are in registers, as long
+        // as the layers involved are HBM-resident (polar_sc8_min_global_log()): bits 24..25 = number of F steps folded in.
+        std::vector<uint32_t> fused;
+        for (size_t i = 0; i < h->sc_ops.size(); ++i) {
+            uint32_t op = h->sc_ops[i];
+            const int type = (int)(op & 7u), sh = (int)((op >> 3) & 15u);
+            if (type <= 1 && N <= 65536) {
+                int extra = 0;
+                while (extra < 2 && i + 1 < h->sc_ops.size()) {
+                    const uint32_t nx = h->sc_ops[i + 1];
+                    if ((nx & 7u) != 0u || (int)((nx >> 3) & 15u) != sh - 1 - extra || sh - 1 - extra < polar_sc8_min_global_log() - 1 || sh - extra < polar_sc8_min_global_log()) break;
+                    ++extra; ++i;
+                }
+                op |= (uint32_t)extra << 24;
+            }
+            fused.push_back(op);
+        }
+        h->sc_ops.swap(fused);
     }
     h->ctl.resize(N);
     for (int i = 0; i < N; ++i) h->ctl[i] = (uint32_t)(h->frozen[i] ? 1u : 0u) | ((uint32_t)h->sched[i] << 1);

@@ -77,6 +77,7 @@ size_t polar_sc8_lds_bytes(int N);
 int polar_sc8_waves_per_block();
 int polar_sc8_waves_per_cu(int N);
 size_t polar_sc8_scratch_doubles_per_wave(int N);
+int polar_sc8_min_global_log();          // log2 of the smallest HBM-resident layer of the list-size-1 kernel
 hipError_t polar_launch_sc8_front(const void *llr, int llr_f32, double *ech_p, unsigned int *flag_words, const double *tabs,
                                   int n, long B, const unsigned *n_dev, hipStream_t st);
 hipError_t polar_launch_sc8_decode(const PolarScParams &p, int grid_waves, hipStream_t st);

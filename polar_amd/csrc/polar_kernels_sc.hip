@@ -65,6 +65,13 @@ constexpr int SC8_SL = SC8_SL_DEF;             // layers of size <= SC8_SL live 
 constexpr int SC8_WPB = SC8_WPB_DEF;           // waves per block (they share the 2.6 KiB of exp/log tables)
 __device__ __forceinline__ int sc8_rowbase(int S) { return S < 8 ? (S == 1 ? 0 : (S == 2 ? 1 : 2)) : (S / 8 + 2); }   // rows: 1,1,1,1,2,4,...
 constexpr int SC8_ROWS = 3 + (2 * SC8_SL / 8 - 1);     // sizes 1, 2, 4 | 8 .. SC8_SL
+// per-wave global scratch: the layers larger than the LDS-resident ones + the decision words [ceil(N/32)][8] (uint32),
+// rounded to whole 512-B rows
+__host__ __device__ static inline size_t sc8_scratch_doubles(int N) {
+    const size_t layers = (N > 2 * SC8_SL) ? (size_t)(N - 2 * SC8_SL) / 8 * 64 : 0;
+    const size_t uwords = (size_t)((N + 31) / 32) * 8;
+    return layers + ((uwords * 4 + 511) / 512) * 64;
+}
 
 template <typename TIN>
 __global__ __launch_bounds__(256) void sc8_front_kernel(const TIN *llr, double *ech_p, unsigned int *flag_words, const double *tabs_g,
@@ -108,13 +115,15 @@ __global__ __launch_bounds__(64 * SC8_WPB) void sc8_decode_kernel(PolarScParams 
     __syncthreads();
     const Tabs tb = {tabs, tabs + 64, tabs + 64 + 129};
     const int words = (N + 31) / 32;
-    const size_t wave_lds = (size_t)SC8_ROWS * 64 * 8 + (size_t)2 * words * 8 * 4;
+    const size_t wave_lds = (size_t)SC8_ROWS * 64 * 8 + (size_t)words * 8 * 4;
     unsigned char *wb = smem + 324 * 8 + (size_t)wib * wave_lds;
     double *lds = reinterpret_cast<double *>(wb);                                  // [SC8_ROWS][64]
     uint32_t *bw = reinterpret_cast<uint32_t *>(wb + (size_t)SC8_ROWS * 64 * 8);   // partial sums [words][8]
-    uint32_t *uw = bw + (size_t)words * 8;                                          // decisions    [words][8]
-    const int big_rows = (N > 2 * SC8_SL) ? (N - 2 * SC8_SL) / 8 : 0;              // rows of the layers 512 .. N/2
-    double *g_a = p.a_scr + (size_t)wave_id * (size_t)big_rows * 64;
+    const int big_rows = (N > 2 * SC8_SL) ? (N - 2 * SC8_SL) / 8 : 0;              // rows of the layers 2 SC8_SL .. N/2
+    double *g_a = p.a_scr + (size_t)wave_id * sc8_scratch_doubles(N);
+    // decisions [words][8]: produced in leaf order, read once at the end -> the wave's global scratch, not the LDS (which
+    // caps the waves per CU); the word under construction is a register of the codeword's first sublane
+    uint32_t *uw = reinterpret_cast<uint32_t *>(g_a + (size_t)big_rows * 64);
     long Bv = p.B;
     if (p.n_dev && (long)*p.n_dev < Bv) Bv = (long)*p.n_dev;
     const long groups = (Bv + 7) / 8;
@@ -126,12 +135,20 @@ __global__ __launch_bounds__(64 * SC8_WPB) void sc8_decode_kernel(PolarScParams 
         const long cw = g * 8 + cws;
         const bool valid = cw < Bv;
         const double *ch = p.ech_t + (size_t)(valid ? cw : 0) * N;               // this codeword's channel values, kernel order
-        for (int i = lane; i < 2 * words * 8; i += 64) bw[i] = 0u;               // (bw and uw are contiguous)
+        for (int i = lane; i < words * 8; i += 64) bw[i] = 0u;
         guard = 0;
+        uint32_t ucur = 0;                 // decisions of word `ucur_w` so far (sublane 0 of each codeword)
+        int ucur_w = -1;                   // wave-uniform
+        auto uflush = [&](int w_new) {
+            if (ucur_w >= 0 && sub == 0) uw[(size_t)ucur_w * 8 + cws] = ucur;
+            ucur = 0;
+            ucur_w = w_new;
+        };
         wave_mem_fence();
         for (int io = 0; io < p.n_ops; ++io) {
             const uint32_t op = ops[io];
-            const int type = (int)(op & 7u), sh = (int)((op >> 3) & 15u), base = (int)(op >> 8);
+            const int type = (int)(op & 7u), sh = (int)((op >> 3) & 15u), base = (int)((op >> 8) & 0xFFFFu);
+            const int extra = (int)((op >> 24) & 3u);                  // F steps of the child chain folded into this visit
             const int S = 1 << sh;
             if (type <= 1) {
                 if (S >= 8) {
@@ -155,6 +172,62 @@ __global__ __launch_bounds__(64 * SC8_WPB) void sc8_decode_kernel(PolarScParams 
                             }
                         }
                     };
+                    // A visit whose output is the input of the F visit that follows (the left descent F F F..., or G then F
+                    // of the right child) evaluates that F - and the next - on its results while they are in registers: the
+                    // layers are still written (their G visits read them later) but not read back (every visit of an
+                    // HBM-resident layer is bandwidth: 62 GB per 262 144 codewords at 5.4 TB/s before this).
+                    // One iteration = one row of the LAST layer of the chain = 2^(D-1) row pairs of the source.
+                    auto visit_chain = [&](const double *src, size_t sstr, auto depth, auto last_on_chip) {
+                        constexpr int D = decltype(depth)::value, NP = 1 << (D - 1);
+                        constexpr bool LL = decltype(last_on_chip)::value;   // the last layer of the chain is the LDS-resident SC8_SL
+                        const int RS = R / NP;                               // rows of the last layer
+                        double *d0 = g_a + (size_t)((S - 2 * SC8_SL) / 8) * 64 + lane;
+                        double *d1g = g_a + (size_t)((LL && D == 2 ? 0 : S / 2 - 2 * SC8_SL) / 8) * 64 + lane;
+                        double *d2g = g_a + (size_t)((LL || D < 3 ? 0 : S / 4 - 2 * SC8_SL) / 8) * 64 + lane;
+                        double *dll = lds + (size_t)sc8_rowbase(SC8_SL) * 64 + lane;
+                        for (int r = 0; r < RS; ++r) {
+                            double a[NP], b[NP], y[NP];
+#pragma unroll
+                            for (int k = 0; k < NP; ++k) { a[k] = src[(size_t)(r + k * RS) * sstr]; b[k] = src[(size_t)(r + k * RS + R) * sstr]; }
+#pragma unroll
+                            for (int k = 0; k < NP; ++k) {
+                                if (type == 0) y[k] = f_node_e(a[k], b[k], guard);
+                                else {
+                                    const int j = base + 8 * (r + k * RS) + sub;
+                                    const uint32_t w = bw[(size_t)(j >> 5) * 8 + cws];
+                                    y[k] = g_node_e(a[k], b[k], w << (31 - (j & 31)), tb);
+                                }
+                                d0[(size_t)(r + k * RS) * 64] = y[k];
+                            }
+#pragma unroll
+                            for (int k = 0; k < NP / 2; ++k) {
+                                y[k] = f_node_e(y[k], y[k + NP / 2], guard);
+                                if constexpr (LL && D == 2) dll[(size_t)(r + k * RS) * 64] = y[k];
+                                else d1g[(size_t)(r + k * RS) * 64] = y[k];
+                            }
+                            if constexpr (D > 2) {
+                                y[0] = f_node_e(y[0], y[1], guard);
+                                if constexpr (LL) dll[(size_t)r * 64] = y[0];
+                                else d2g[(size_t)r * 64] = y[0];
+                            }
+                        }
+                    };
+                    if (extra) {
+                        typedef std::integral_constant<int, 2> D2;
+                        typedef std::integral_constant<int, 3> D3;
+                        const bool ll = (S >> extra) <= SC8_SL;
+                        if (2 * S == N) {
+                            const double *sc = ch + sub;
+                            if (extra == 1) { if (ll) visit_chain(sc, 8, D2(), std::true_type()); else visit_chain(sc, 8, D2(), std::false_type()); }
+                            else { if (ll) visit_chain(sc, 8, D3(), std::true_type()); else visit_chain(sc, 8, D3(), std::false_type()); }
+                        } else {
+                            const double *sg = g_a + (size_t)((2 * S - 2 * SC8_SL) / 8) * 64 + lane;
+                            if (extra == 1) { if (ll) visit_chain(sg, 64, D2(), std::true_type()); else visit_chain(sg, 64, D2(), std::false_type()); }
+                            else { if (ll) visit_chain(sg, 64, D3(), std::true_type()); else visit_chain(sg, 64, D3(), std::false_type()); }
+                        }
+                        wave_mem_fence();
+                        continue;
+                    }
                     double *dl = lds + (size_t)sc8_rowbase(S) * 64 + lane;
                     double *dg = g_a + (size_t)((S - 2 * SC8_SL) / 8) * 64 + lane;
                     if (2 * S == N) {                      // source = channel: 8 consecutive doubles per codeword and row
@@ -200,19 +273,21 @@ __global__ __launch_bounds__(64 * SC8_WPB) void sc8_decode_kernel(PolarScParams 
                 }
                 guard |= __builtin_amdgcn_ballot_w64(zero);
                 wave_mem_fence();
-                if (sub == 0) {
-                    if (S <= 32) {
+                if (S <= 32) {
+                    if ((base >> 5) != ucur_w) uflush(base >> 5);
+                    if (sub == 0) {
                         const int sft = base & 31;
                         const uint32_t m = (S == 32) ? 0xFFFFFFFFu : ((1u << S) - 1u);
                         const uint32_t x = (bw[(size_t)(base >> 5) * 8 + cws] >> sft) & m;
-                        uw[(size_t)(base >> 5) * 8 + cws] |= (uint32_t)bits_transform((u64)x, S) << sft;
-                    } else {
-                        const int nw = S / 32, w0b = base >> 5;
-                        for (int b0 = 0; b0 < nw; ++b0) {
-                            uint32_t x = 0;
-                            for (int b1 = b0; b1 < nw; ++b1) if ((b1 & b0) == b0) x ^= bw[(size_t)(w0b + b1) * 8 + cws];
-                            uw[(size_t)(w0b + b0) * 8 + cws] = (uint32_t)bits_transform((u64)x, 32);
-                        }
+                        ucur |= (uint32_t)bits_transform((u64)x, S) << sft;
+                    }
+                } else if (sub == 0) {
+                    // whole words: straight to the scratch (the word under construction is an earlier one)
+                    const int nw = S / 32, w0b = base >> 5;
+                    for (int b0 = 0; b0 < nw; ++b0) {
+                        uint32_t x = 0;
+                        for (int b1 = b0; b1 < nw; ++b1) if ((b1 & b0) == b0) x ^= bw[(size_t)(w0b + b1) * 8 + cws];
+                        uw[(size_t)(w0b + b0) * 8 + cws] = (uint32_t)bits_transform((u64)x, 32);
                     }
                 }
                 wave_mem_fence();
@@ -254,6 +329,7 @@ __global__ __launch_bounds__(64 * SC8_WPB) void sc8_decode_kernel(PolarScParams 
                 guard |= __builtin_amdgcn_ballot_w64(bad);
             }
         }
+        uflush(-1);
         wave_mem_fence();
         if (valid && sub == 0 && ((guard >> (8 * cws)) & 0xFFull)) atomicOr(&p.flag_words[cw >> 5], 1u << (cw & 31));
         // ---- info bits, one codeword at a time across the wave
@@ -275,10 +351,11 @@ __global__ __launch_bounds__(64 * SC8_WPB) void sc8_decode_kernel(PolarScParams 
         }
     }
 }
-size_t polar_sc8_lds_bytes(int N) { return 324 * 8 + (size_t)SC8_WPB * ((size_t)SC8_ROWS * 64 * 8 + (size_t)2 * ((N + 31) / 32) * 8 * 4); }
+size_t polar_sc8_lds_bytes(int N) { return 324 * 8 + (size_t)SC8_WPB * ((size_t)SC8_ROWS * 64 * 8 + (size_t)((N + 31) / 32) * 8 * 4); }
 int polar_sc8_waves_per_block() { return SC8_WPB; }
+int polar_sc8_min_global_log() { int l = 0; while ((1 << l) < 2 * SC8_SL) ++l; return l; }
 int polar_sc8_waves_per_cu(int N) { const int w = (int)((160 * 1024) / polar_sc8_lds_bytes(N)) * SC8_WPB; return w > 32 ? 32 : w; }
-size_t polar_sc8_scratch_doubles_per_wave(int N) { return (N > 2 * SC8_SL) ? (size_t)(N - 2 * SC8_SL) / 8 * 64 : 0; }
+size_t polar_sc8_scratch_doubles_per_wave(int N) { return sc8_scratch_doubles(N); }
 hipError_t polar_launch_sc8_front(const void *llr, int llr_f32, double *ech_p, unsigned int *flag_words, const double *tabs,
                                   int n, long B, const unsigned *n_dev, hipStream_t st) {
     const unsigned blocks = (unsigned)(B < 65536 ? (B ? B : 1) : 65536);
