@@ -347,6 +347,11 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         }
 
         PROF_DECL
+#ifdef POLAR_MARGIN
+        // development aid (tools/margin_profile.py): the smallest gap, over all pruning fork steps of this codeword, between
+        // the worst surviving and the best discarded fork metric — what a lower-precision state would have to resolve
+        double mingap = __builtin_inf();
+#endif
         // per-leaf control word (frozen flag, rate-0 block size): a SCALAR load through the constant
         // address space, issued one leaf ahead — as a plain global load it is a vector memory round
         // trip on the critical path of every leaf
@@ -945,6 +950,13 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 PROF(16)
                 if (fast) {
                     PROF_CNT(9, 1)
+#ifdef POLAR_MARGIN
+                    {
+                        const double gx = group_reduce<GS, true>(active ? gm : -__builtin_inf(), lane);
+                        const double bx = group_reduce<GS, false>(active ? pm + spos : __builtin_inf(), lane);
+                        if (nact == L) mingap = __builtin_fmin(mingap, bx - gx);
+                    }
+#endif
                     if (active) {
                         ubit = lneg ? 1u : 0u;
                         pm = gm;
@@ -1101,6 +1113,15 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                         c0 = goodbit ? sbd : sg;
                         c1 = goodbit ? sg : sbd;
                     }
+#ifdef POLAR_MARGIN
+                    {
+                        const double ninf = -__builtin_inf(), pinf = __builtin_inf();
+                        const double sv = __builtin_fmax(sg ? mg : ninf, sbd ? mb : ninf);
+                        const double kv = __builtin_fmin((active && !sg) ? mg : pinf, (active && !sbd) ? mb : pinf);
+                        const double sx = group_reduce<GS, true>(sv, lane), kx = group_reduce<GS, false>(kv, lane);
+                        if (full) mingap = __builtin_fmin(mingap, kx - sx);
+                    }
+#endif
                     wave_mem_fence();
                 } else {
                     sortbuf[2 * lane] = pf0;
@@ -1244,6 +1265,13 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         }
         // no candidate with PM < DBL_MAX: the reference returns l_p = 0 (PolarCode.cpp:611,626)
         const int win = (key < __builtin_inf()) ? kidx : 0;
+#ifdef POLAR_MARGIN
+        double fingap;
+        {   // final selection: runner-up candidate metric - winner's
+            const double mine = (cand && pm < 1.7976931348623157e308 && lig != win) ? pm : __builtin_inf();
+            fingap = group_reduce<GS, false>(mine, lane) - key;
+        }
+#endif
         const double pm_win = shfl_d(pm, gbase + win);
         if (valid) {
 #ifndef POLAR_PROFILE
@@ -1271,6 +1299,13 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
             if (valid && lig == 0 && ((guard >> gbase) & gmask) != 0) p.flags[cw] = 1;
         }
         wave_mem_fence();
+#ifdef POLAR_MARGIN
+        if (valid && lig == 0 && K >= 16) {      // (overwrites the first 16 info bytes: this build measures, it does not decode)
+            double *o = reinterpret_cast<double *>(p.out + (size_t)cw * K);
+            o[0] = mingap; o[1] = fingap;
+        }
+        wave_mem_fence();
+#endif
         // next group
         if (p.work) {
             unsigned nxt = 0;
