@@ -226,6 +226,15 @@ def test_winning_path_metric_matches_oracle(built_lib, oracle_built, n, K, crc, 
         assert abs(got[i] - want) <= 1e-10 * max(1.0, abs(want)), (i, got[i], want)
 
 
+@pytest.mark.parametrize("n,K,crc,B", [(13, 4096, 0, 40), (14, 8192, 24, 24), (15, 16384, 0, 11), (12, 3000, 8, 64), (6, 40, 0, 100)])
+def test_list_size_one_long_codes(built_lib, oracle_built, n, K, crc, B):
+    """L = 1 (pruned SC kernel) beyond the sizes whose channel row is permuted through LDS (n > 12: scattered stores of the
+    conversion kernel), with the deepest fused F-chains, ragged batches (not multiples of the eight codewords per wave)."""
+    o, g = _pair(n, K, crc)
+    llr, _ = o.synth_llr(707, 0, B, o.snr_sqrt_linear(1.5))
+    assert (o.decode_scl_llr(llr, 1) == g.decode_scl_llr(llr, 1)).all()
+
+
 @pytest.mark.parametrize("n,K,crc,L,B", [(12, 2048, 16, 8, 24), (13, 4096, 0, 4, 16), (14, 8192, 24, 2, 8),
                                          (15, 16384, 32, 32, 4), (11, 1024, 32, 64, 12), (7, 100, 7, 16, 64)])
 def test_long_codes_and_extreme_parameters(built_lib, oracle_built, n, K, crc, L, B):
