@@ -145,7 +145,8 @@ int polar_get_bler_quick_ber(polar_code_t *h, const double *ebno, int n_e, const
  * own copy of the code tables and scratch (owned by `h`); the round's counters are summed with one RCCL
  * ncclAllReduce(uint64, sum) over xGMI (bound at run time; a host-side sum when RCCL cannot be loaded, or with
  * POLAR_NO_RCCL set). Counter-based inputs make the result independent of n_dev. *used_rccl (optional) reports
- * which path summed the counters. ber_out may be NULL. */
+ * which path summed the counters. ber_out may be NULL. A device may be listed once; the test hook POLAR_TEST_SHARE_DEVICE
+ * (environment) lifts that so that one GPU can stand in for several (separate contexts and worker threads, host-side sum). */
 int polar_get_bler_quick_multi(polar_code_t *h, const int *devices, int n_dev, const double *ebno, int n_e,
                                const uint8_t *L, int n_L, long max_runs, long max_err, uint64_t seed, long batch,
                                double *bler_out, double *ber_out, int *used_rccl);

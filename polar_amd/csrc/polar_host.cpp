@@ -380,8 +380,16 @@ int polar_get_crc_matrix(const polar_code_t *h, uint8_t *m) {
     if (h->crc) memcpy(m, h->crcm.data(), (size_t)h->crc * h->K);
     return POLAR_OK;
 }
+// the per-device contexts of polar_get_bler_quick_multi are copies of the handle's tables and settings: any setter
+// drops them (they are rebuilt by the next multi-device call)
+static void drop_clones(polar_code_t *h) {
+    for (polar_code *c : h->clones) polar_destroy(c);
+    h->clones.clear();
+}
+
 int polar_set_crc_matrix(polar_code_t *h, const uint8_t *m) {
     if (!h || (!m && h->crc)) return fail(POLAR_E_ARG, "NULL argument");
+    drop_clones(h);
     if (h->crc) memcpy(h->crcm.data(), m, (size_t)h->crc * h->K);
     int rc = derive_tables(h);
     if (rc) return rc;
@@ -400,6 +408,7 @@ int polar_set_tuning(polar_code_t *h, int waves_per_cu, int lds_log) {
         return fail(POLAR_E_ARG, "lds_log = 2 exists only for the 4-wave-block kernels (waves_per_cu > 8)");
     h->waves_per_cu = waves_per_cu;
     h->lds_log = lds_log;
+    drop_clones(h);
     return POLAR_OK;
 }
 
@@ -407,6 +416,7 @@ int polar_set_mode(polar_code_t *h, int mode) {
     if (!h) return fail(POLAR_E_ARG, "NULL handle");
     if (mode < 0 || mode > 2) return fail(POLAR_E_ARG, "mode must be 0 (auto), 1 (LLR-domain) or 2 (exp-domain)");
     h->mode = mode;
+    drop_clones(h);
     return POLAR_OK;
 }
 
@@ -949,15 +959,19 @@ Rccl g_rccl;
 constexpr int kNcclUint64 = 5, kNcclSum = 0;     // rccl.h: ncclUint64, ncclSum
 
 // the handle's tables on another device (owned by `h`, reused by later calls)
-polar_code *clone_on_device(polar_code *h, int dev) {
-    if (dev == h->device) return h;
-    for (polar_code *c : h->clones) if (c->device == dev) return c;
+polar_code *clone_on_device(polar_code *h, int dev, bool fresh = false) {
+    // fresh: a context of its own even when one exists for this device (test hook POLAR_TEST_SHARE_DEVICE)
+    if (!fresh) {
+        if (dev == h->device) return h;
+        for (polar_code *c : h->clones) if (c->device == dev) return c;
+    }
     polar_code *c = new polar_code;
     c->n = h->n; c->N = h->N; c->K = h->K; c->crc = h->crc; c->eps = h->eps;
     c->frozen = h->frozen; c->order = h->order; c->bitrev = h->bitrev; c->crcm = h->crcm;
     c->W = h->W; c->info_rank = h->info_rank; c->crc_mask = h->crc_mask; c->sched = h->sched; c->ctl = h->ctl;
+    c->sc_ops = h->sc_ops;
     c->device = dev;
-    c->waves_per_cu = h->waves_per_cu; c->lds_log = h->lds_log; c->prefix_on = h->prefix_on; c->mode = h->mode;
+    c->waves_per_cu = h->waves_per_cu; c->lds_log = h->lds_log; c->pipe = h->pipe; c->prefix_on = h->prefix_on; c->mode = h->mode;
     h->clones.push_back(c);
     return c;
 }
@@ -985,14 +999,23 @@ int bler_impl(polar_code_t *h, const int *devices, int n_dev, const double *ebno
     std::vector<polar_code *> ctx(n_dev);
     std::vector<hipStream_t> streams(n_dev, nullptr);
     int ndev_visible = 0;
+    bool dup = false;
     if (hipGetDeviceCount(&ndev_visible) != hipSuccess || ndev_visible <= 0)
         return fail(POLAR_E_DEVICE, "no HIP device available; this library has no CPU decode path");
     for (int d = 0; d < n_dev; ++d) {
         const int dev = devices ? devices[d] : d;
         if (dev < 0 || dev >= ndev_visible) return fail(POLAR_E_ARG, "device %d not visible (%d devices)", dev, ndev_visible);
-        for (int e = 0; e < d; ++e) if ((devices ? devices[e] : e) == dev) return fail(POLAR_E_ARG, "device %d listed twice", dev);
+        // (test hook: POLAR_TEST_SHARE_DEVICE lets one GPU stand in for several, so that the per-device contexts, worker
+        // threads, strided trial partition and counter sum are exercised on a single-GPU box; RCCL cannot have two ranks
+        // on one device, the counters are then summed on the host)
+        bool again = false;
+        for (int e = 0; e < d; ++e)
+            if ((devices ? devices[e] : e) == dev) {
+                if (!getenv("POLAR_TEST_SHARE_DEVICE")) return fail(POLAR_E_ARG, "device %d listed twice", dev);
+                dup = again = true;
+            }
         if (h->device < 0 && d == 0) h->device = dev;
-        ctx[d] = clone_on_device(h, dev);
+        ctx[d] = clone_on_device(h, dev, again);
         DevGuard g2;
         int rc = ensure_device(ctx[d], g2);
         g2.prev = -1;
@@ -1003,7 +1026,7 @@ int bler_impl(polar_code_t *h, const int *devices, int n_dev, const double *ebno
     // RCCL communicators (single process, one rank per device); without RCCL the counters are summed on the host
     std::vector<void *> comms(n_dev, nullptr);
     bool rccl = false;
-    if ((n_dev > 1 || getenv("POLAR_FORCE_RCCL")) && !getenv("POLAR_NO_RCCL") && g_rccl.load()) {
+    if ((n_dev > 1 || getenv("POLAR_FORCE_RCCL")) && !getenv("POLAR_NO_RCCL") && !dup && g_rccl.load()) {
         std::vector<int> devs(n_dev);
         for (int d = 0; d < n_dev; ++d) devs[d] = ctx[d]->device;
         rccl = (g_rccl.CommInitAll(comms.data(), n_dev, devs.data()) == 0);

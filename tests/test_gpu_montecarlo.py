@@ -80,6 +80,29 @@ def test_multi_gpu_entry_point_one_device_through_rccl(built_lib, oracle_built):
     assert (got2 == want).all()
 
 
+def test_multi_device_partition_with_one_gpu_standing_in_for_several(built_lib, oracle_built, monkeypatch):
+    """The single-process multi-GPU driver (per-device table clones, one worker thread and stream per device, trials
+    done + d, done + d + n_dev, ..., counter sum) with ONE GPU listed two / three / five times (test hook
+    POLAR_TEST_SHARE_DEVICE; RCCL cannot have two ranks on a device, so the counters are summed on the host): the
+    estimates must be those of the single-device run — the union of the trials does not depend on the partition."""
+    o, g = _pair(8, 128, 8)
+    ebno, Ls = [0.5, 2.0], [1, 4, 8]
+    want, want_ber = g.get_bler_quick(ebno, Ls, max_runs=1500, max_err=60, seed=77, batch=250, return_ber=True)
+    monkeypatch.setenv("POLAR_TEST_SHARE_DEVICE", "1")
+    for devs in ([0, 0], [0, 0, 0], [0] * 5):
+        got, got_ber = g.get_bler_quick(ebno, Ls, max_runs=1500, max_err=60, seed=77, batch=250, return_ber=True, devices=devs)
+        assert np.array_equal(np.asarray(got), np.asarray(want)), devs
+        assert np.array_equal(np.asarray(got_ber), np.asarray(want_ber)), devs
+    # a setter after the per-device contexts exist: they must not keep the old CRC matrix
+    m = g.crc_matrix.copy()
+    m[:, ::3] ^= 1
+    g.crc_matrix = m
+    want2 = g.get_bler_quick(ebno, [8], max_runs=500, max_err=10**6, seed=5, batch=500)
+    got2 = g.get_bler_quick(ebno, [8], max_runs=500, max_err=10**6, seed=5, batch=500, devices=[0, 0, 0])
+    assert np.array_equal(np.asarray(got2), np.asarray(want2))
+    assert not np.array_equal(np.asarray(want2), np.asarray(want)[2:3])     # (the matrix matters: different estimates)
+
+
 def test_handle_keeps_callers_device_and_rejects_bad_devices(built_lib):
     import torch
     import polar_amd
