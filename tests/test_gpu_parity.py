@@ -226,6 +226,15 @@ def test_winning_path_metric_matches_oracle(built_lib, oracle_built, n, K, crc, 
         assert abs(got[i] - want) <= 1e-10 * max(1.0, abs(want)), (i, got[i], want)
 
 
+@pytest.mark.parametrize("n,K,crc", [(1, 1, 0), (2, 2, 0), (2, 3, 0), (3, 4, 0), (3, 5, 1), (3, 8, 0), (4, 8, 0), (4, 11, 2), (4, 1, 0)])
+def test_tiny_block_lengths(built_lib, oracle_built, n, K, crc):
+    """N = 2 .. 16: fewer elements than a row of the L = 1 kernel holds, all-unfrozen and single-bit codes."""
+    o, g = _pair(n, K, crc)
+    llr, _ = o.synth_llr(5, 0, 300, o.snr_sqrt_linear(1.0))
+    for L in (1, 2, 4, 8, 32):
+        assert (o.decode_scl_llr(llr, L) == g.decode_scl_llr(llr, L)).all(), L
+
+
 @pytest.mark.parametrize("n,K,crc,B", [(13, 4096, 0, 40), (14, 8192, 24, 24), (15, 16384, 0, 11), (12, 3000, 8, 64), (6, 40, 0, 100)])
 def test_list_size_one_long_codes(built_lib, oracle_built, n, K, crc, B):
     """L = 1 (pruned SC kernel) beyond the sizes whose channel row is permuted through LDS (n > 12: scattered stores of the
