@@ -1327,8 +1327,12 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
 // LLRs; (3) the path metric accumulated over the first Pe leaves in order, same operations and order
 // as continuePaths_FrozenBit (PolarCode.cpp:475-487) -> pre[cw][0].
 template <bool ED>
-__global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p) {
+__global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p, int staged) {
     __shared__ double tabs[324];
+    // staged: the first pass (channel -> layer N/2) reads the channel pairs in their own order — element j of the layer comes
+    // from the pair at bitrev(j), a 16-B read from a different line for every lane when read in element order — and
+    // turns the results into element order through LDS ([8 codewords][N/2] doubles, dynamic)
+    extern __shared__ double pstage[];
 
     for (int i = threadIdx.x; i < 322; i += 256) tabs[i] = p.tabs[i];
     __syncthreads();
@@ -1352,7 +1356,24 @@ __global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p) {
         double *pre = const_cast<double *>(p.pre) + (size_t)(valid ? cw : 0) * (size_t)(N - Q + 1);
         double x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int S = N / 2; S >= Q; S >>= 1) {
-            if (valid) {
+            if (valid && staged && 2 * S == N) {
+                double *stg = pstage + (size_t)(threadIdx.x >> 5) * (size_t)S;
+                double *outp = pre + 1;
+                for (int m = lig; m < S; m += 32) {
+                    const double r = FN(CH(in0, 2 * m), CH(in0, 2 * m + 1));
+                    stg[__brev((unsigned)m) >> (33 - n)] = r;                  // element j = bitrev_{n-1}(m)
+                }
+                wave_mem_fence();                                            // (the 32 lanes of a codeword are in one wave)
+                for (int j = lig; j < S; j += 32) {
+                    const double r = stg[j];
+                    outp[j] = r;
+                    if (S == Q) {
+#pragma unroll
+                        for (int rr = 0; rr < 8; ++rr) if (rr == (j >> 5)) x[rr] = r;
+                    }
+                }
+                wave_mem_fence();
+            } else if (valid) {
                 const bool from_ch = (2 * S == N);
                 const double *inp = pre + 1 + (size_t)(N - 4 * S);      // layer of size 2S (unused when from_ch)
                 double *outp = pre + 1 + (size_t)(N - 2 * S);
@@ -1436,7 +1457,13 @@ __global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p) {
                 leaf_terms<ED>(x[r], true, tb, ng, al, sneg, spos);
                 const double spv = ng ? spos : sneg;
                 const int cnt = (Pe - r * 32 < 32) ? (Pe - r * 32) : 32;
-                for (int c = 0; c < cnt; ++c) acc += shfl_d(spv, gbase + c);
+                // (the sum must run in leaf order; unrolled, the 32 cross-lane reads are in flight together and only the
+                // additions are serial)
+#pragma unroll
+                for (int c = 0; c < 32; ++c) {
+                    const double t = shfl_d(spv, gbase + c);
+                    acc = (c < cnt) ? acc + t : acc;
+                }
             }
         }
         if (valid && lig == 0) pre[0] = acc;
@@ -1460,7 +1487,9 @@ hipError_t polar_launch_prefix_ed0(const PolarDecodeParams &p, hipStream_t st) {
 #endif
     long blocks = (p.B + 7) / 8;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(prefix_kernel<POLAR_ED_TU != 0>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    const size_t stage = (size_t)8 * (size_t)(p.N / 2) * sizeof(double);        // 64 KiB at N = 2048: two blocks per CU
+    const int staged = (p.N >= 64 && stage <= 64 * 1024) ? 1 : 0;
+    hipLaunchKernelGGL(prefix_kernel<POLAR_ED_TU != 0>, dim3((unsigned)blocks), dim3(256), staged ? stage : 0, st, p, staged);
     return hipGetLastError();
 }
 
