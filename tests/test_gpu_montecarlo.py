@@ -103,6 +103,26 @@ def test_multi_device_partition_with_one_gpu_standing_in_for_several(built_lib, 
     assert not np.array_equal(np.asarray(want2), np.asarray(want)[2:3])     # (the matrix matters: different estimates)
 
 
+def test_python_sharded_driver_and_strided_engine_on_the_gpu(built_lib, oracle_built):
+    """polar_amd/montecarlo.py (the multi-process form bench.py / torchrun use) with the real GPU engine `mc_batch`:
+    world size 1 equals the native driver round for round; and the engine's strided trial partition — rank r of a
+    world of 3 simulates trials base + r, base + r + 3, ... — sums to the unpartitioned counters."""
+    from polar_amd.montecarlo import get_bler_quick_sharded
+    o, g = _pair(8, 128, 8)
+    ebno, Ls = [0.5, 2.0], [1, 4]
+    want = g.get_bler_quick(ebno, Ls, max_runs=1200, max_err=50, seed=11, batch=300)
+    bler, err, run = get_bler_quick_sharded(g.mc_batch, ebno, Ls, max_runs=1200, max_err=50, seed=11, global_batch=300)
+    assert np.array_equal(np.asarray(bler), np.asarray(want))
+    P = (len(Ls), len(ebno))
+    en = np.ones(P, np.uint8)
+    e_all, r_all = np.zeros(P, np.uint64), np.zeros(P, np.uint64)
+    g.mc_batch(11, 40, 501, 1, ebno, Ls, en, e_all, r_all)
+    e_sum, r_sum = np.zeros(P, np.uint64), np.zeros(P, np.uint64)
+    for r in range(3):
+        g.mc_batch(11, 40 + r, len(range(r, 501, 3)), 3, ebno, Ls, en, e_sum, r_sum)
+    assert np.array_equal(e_sum, e_all) and np.array_equal(r_sum, r_all)
+
+
 def test_handle_keeps_callers_device_and_rejects_bad_devices(built_lib):
     import torch
     import polar_amd
