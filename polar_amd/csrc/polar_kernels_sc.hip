@@ -256,12 +256,24 @@ __global__ __launch_bounds__(64 * SC8_WPB) void sc8_decode_kernel(PolarScParams 
                                                                       : g_a + (size_t)((S - 2 * SC8_SL) / 8) * 64 + lane);
                 const int R = S >= 8 ? S / 8 : 1;
                 bool zero = false;
+                // The reference does not decide by the sign of the leaf LLR but by comparing PM + log(1+e^-llr) with
+                // PM + log(1+e^llr) (PolarCode.cpp:505-506): below the rounding granularity of PM (<= 1e-11 for any PM this
+                // decoder can reach) the two are EQUAL and the tie goes to bit 0. The smallest leaf magnitude of an
+                // all-unfrozen node is its first leaf's, 2 atanh(prod tanh(|x_i| / 2)) over the root values; tanh(|x|/2) =
+                // (1-E)/(1+E) >= 1 - 2E. Codewords whose product falls below 1e-8 (a node in the worst channels: only with
+                // unfrozen sets no construction produces) go to the general kernel, which keeps the metric.
+                double q = 1.0;
                 for (int r4 = 0; r4 < R; r4 += 4) {
                     uint32_t acc = 0;
                     for (int k = 0; k < 4 && r4 + k < R; ++k) {
                         const double v = (S == N) ? ch[(size_t)(r4 + k) * 8 + sub] : src[(size_t)(r4 + k) * 64];
                         const bool in = (S >= 8) || sub < S;
                         zero |= in && fabs(v) == 1.0;
+                        {
+                            const double m = fabs(v);
+                            const double t = in ? __builtin_fmax(1.0 - 2.0 * ((m > 1.0) ? 0.0 : m), 0.0) : 1.0;
+                            q = __builtin_fmax(q * t, 1e-300);
+                        }
                         const u64 bal = __builtin_amdgcn_ballot_w64(in && ed_is_neg(v));
                         acc |= (uint32_t)((bal >> (8 * cws)) & 0xFFull) << (8 * k);
                     }
@@ -272,6 +284,22 @@ __global__ __launch_bounds__(64 * SC8_WPB) void sc8_decode_kernel(PolarScParams 
                     }
                 }
                 guard |= __builtin_amdgcn_ballot_w64(zero);
+#pragma unroll
+                for (int off = 1; off < 8; off <<= 1) q = __builtin_fmax(q * __shfl_xor(q, off, 64), 1e-300);
+                if (__builtin_amdgcn_ballot_w64(q < 1e-8)) {
+                    // the cheap bound failed somewhere in the wave: the product itself (a division per root value)
+                    double T = 1.0;
+                    for (int r = 0; r < R; ++r) {
+                        const double v = (S == N) ? ch[(size_t)r * 8 + sub] : src[(size_t)r * 64];
+                        const bool in = (S >= 8) || sub < S;
+                        const double m = __builtin_fmin(fabs(v), 1.0);
+                        const double t = (in && fabs(v) <= 1.0) ? ed_div(1.0 - m, 1.0 + m) : 1.0;
+                        T = __builtin_fmax(T * t, 1e-300);
+                    }
+#pragma unroll
+                    for (int off = 1; off < 8; off <<= 1) T = __builtin_fmax(T * __shfl_xor(T, off, 64), 1e-300);
+                    guard |= __builtin_amdgcn_ballot_w64(T < 1e-8);
+                }
                 wave_mem_fence();
                 if (S <= 32) {
                     if ((base >> 5) != ucur_w) uflush(base >> 5);
