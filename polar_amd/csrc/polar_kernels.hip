@@ -1273,6 +1273,11 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         }
 #endif
         const double pm_win = shfl_d(pm, gbase + win);
+        // No candidate with a finite metric (every path met a frozen leaf with llr < -709.78: the reference's log(1+e^-llr)
+        // is +inf there) AND the list never filled (more list entries than 2^K paths): the reference's l_p = 0 is a path that
+        // was never activated, its info array still holds the zeros of initializeDataStructures (PolarCode.cpp:195-230).
+        // (Found by tools/fuzz_parity.py; this read used to return whatever an earlier codeword left in the slot.)
+        const bool win_active = __shfl((int)active, gbase + win, 64) != 0;
         if (valid) {
 #ifndef POLAR_PROFILE
             if (p.pm_out && lig == 0) p.pm_out[cw] = pm_win;
@@ -1291,7 +1296,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
             for (int b = lig; b < K; b += GS) {
                 unsigned r = p.info_rank[b];
                 uint32_t wd = g_tb[(size_t)(r >> 5) * 64 + lane];
-                p.out[(size_t)cw * K + b] = (uint8_t)((wd >> (r & 31)) & 1u);
+                p.out[(size_t)cw * K + b] = win_active ? (uint8_t)((wd >> (r & 31)) & 1u) : (uint8_t)0;
             }
         }
         if constexpr (ED) {

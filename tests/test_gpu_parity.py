@@ -226,6 +226,21 @@ def test_winning_path_metric_matches_oracle(built_lib, oracle_built, n, K, crc, 
         assert abs(got[i] - want) <= 1e-10 * max(1.0, abs(want)), (i, got[i], want)
 
 
+def test_no_finite_candidate_and_a_list_that_never_filled(built_lib, oracle_built):
+    """Every path meets a frozen leaf with llr < -709.78 (path metric +inf) and the list has more entries than 2^K paths:
+    the reference returns l_p = 0, a path that was never activated — the zeros of initializeDataStructures
+    (PolarCode.cpp:195-230, 609-644). Found by tools/fuzz_parity.py."""
+    o, g = _pair(4, 3, 0)
+    llr = np.zeros((4, 16))
+    llr[0] = np.where(np.arange(16) % 2 == 0, 1e3, -1e3)
+    llr[1], llr[2], llr[3] = 0.5 * llr[0], 0.7 * llr[0], 0.8 * llr[0]
+    for L in (1, 2, 4, 8, 16, 24, 32, 64):
+        want = o.decode_scl_llr(llr, L)
+        for mode in (0, 1):
+            g.set_mode(mode)
+            assert (g.decode_scl_llr(llr, L) == want).all(), (L, mode)
+
+
 @pytest.mark.parametrize("n,F", [(9, 256), (10, 64), (10, 256), (11, 128), (11, 256)])
 def test_list_size_one_unfrozen_leaves_in_the_worst_channels(built_lib, oracle_built, n, F):
     """Explicit tables no construction produces: the first F leaves frozen, every other leaf unfrozen. The first unfrozen
