@@ -44,13 +44,42 @@ def main():
     ap.add_argument("--lds-log", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="codewords for the CPU baseline (-1 = auto, 0 = skip)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short timings of BASELINE.json configs 1, 2, 3, 5")
+    ap.add_argument("--dry-run-gloo", action="store_true",
+                    help="launcher / rendezvous / counter all-reduce only, on CPU over gloo: no kernel runs, the line carries "
+                         "\"dry_run\": true and no throughput (tests/test_bench_launcher.py)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (one rank per GPU, RCCL over xGMI). Checked BEFORE
+        # spawning, so that a box with fewer GPUs fails here with one clear message instead of N tracebacks.
+        if not args.dry_run_gloo:
+            have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            if have < args.gpus:
+                raise SystemExit(f"bench.py: --gpus {args.gpus} requested but {have} GPU(s) visible; refusing to run "
+                                 f"a {args.gpus}-GPU benchmark on fewer devices")
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}: the two must agree "
+                         f"(n_gpus in the result line is the number of ranks that really ran)")
+    if args.dry_run_gloo:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("BENCH_FORCE_DIST"):
@@ -201,6 +230,33 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         print(json.dumps(res), flush=True)     # the ONE JSON line, last thing on stdout
+
+
+def dry_run(args, world, rank):
+    """The multi-process skeleton of main() without a GPU: rendezvous, barrier-bracketed timed region, counter
+    all-reduce, max-over-ranks time, one JSON line from rank 0. Runs on CPU over gloo; measures nothing."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    dist.init_process_group(backend="gloo")
+    counters = torch.zeros(2, dtype=torch.int64)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        counters[1] += args.batch            # the trials this rank would have decoded (shard rank*batch ...)
+    dist.all_reduce(counters)
+    dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "codewords/s (N=2048 K=1024 L=32 LLR-SCL)", "value": None, "unit": "codewords/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                          "runs_all_ranks": int(counters[1]), "scaling": "weak",
+                          "config": {"workload": "dry run (gloo, CPU): launcher and counter reduction only"}}), flush=True)
 
 
 def traffic_from_profile(args, B):

@@ -151,6 +151,11 @@ int polar_get_bler_quick_multi(polar_code_t *h, const int *devices, int n_dev, c
                                const uint8_t *L, int n_L, long max_runs, long max_err, uint64_t seed, long batch,
                                double *bler_out, double *ber_out, int *used_rccl);
 
+/* test hook: number of ncclCommInitAll calls made by this library so far (the communicators and streams of a device
+ * list are cached on the handle: a second polar_get_bler_quick_multi with the same list makes none). When a device's
+ * round fails, no device enters the round's collective, the communicators are aborted and the call returns the error. */
+int polar_debug_comm_inits(void);
+
 /* step-wise Monte-Carlo for multi-GPU drivers: simulate trials {t0 + i*stride : i < T} for
  * every enabled (L, Eb/N0) point and ADD to err/run (host uint64 [n_L*n_e]). */
 int polar_mc_batch(polar_code_t *h, uint64_t seed, uint64_t t0, long T, long stride,

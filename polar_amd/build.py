@@ -42,7 +42,19 @@ def _newer(target, deps):
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in deps)
+
+
+def _deps(obj, fallback):
+    """Headers an object really includes (the compiler's -MD file next to it); every header when there is none yet."""
+    d = obj + ".d"
+    if not os.path.exists(d):
+        return fallback
+    txt = open(d).read().replace("\\\n", " ")
+    parts = txt.split(":", 1)
+    if len(parts) < 2:
+        return fallback
+    return [x for x in parts[1].split() if x.startswith(ROOT)]
 
 
 def build(force=False, verbose=False, profile=False):
@@ -63,9 +75,10 @@ def build(force=False, verbose=False, profile=False):
         src = os.path.join(CSRC, s)
         obj = os.path.join(BUILD, s + otag + tag + ".o")
         objs.append(obj)
-        if force or _newer(obj, [src] + headers + [os.path.abspath(__file__)]):
+        if force or _newer(obj, [src] + _deps(obj, headers)):
             cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-                   "-Wall", "-Wno-unused-function", "-x", "hip", "-I", INC, "-I", CSRC, "-c", src, "-o", obj]
+                   "-Wall", "-Wno-unused-function", "-x", "hip", "-I", INC, "-I", CSRC, "-MD", "-MF", obj + ".d",
+                   "-c", src, "-o", obj]
             if profile:
                 cmd.insert(1, "-DPOLAR_PROFILE")
             for d in defs + os.environ.get("POLAR_DEFS", "").split():

@@ -85,11 +85,13 @@ __device__ __forceinline__ unsigned group_reduce_u32(unsigned v) {
 // placement as group_reduce_u32 (group_result_rows).
 template <int GS>
 __device__ __forceinline__ void group_max_min_u32(unsigned &a, unsigned &b) {
+// (every stage carries BOTH wait states of its first DPP read inside its own asm statement: the compiler's hazard
+// recognizer does not look into inline asm and may move the VALU producer of `a` right in front of it; the second
+// instruction of a stage is covered by the first one)
 #define POLAR_DPP_STAGE(CTRL)                                           \
-    asm volatile("s_nop 0\n\t"                                          \
+    asm volatile("s_nop 1\n\t"                                         \
                  "v_max_u32_dpp %0, %0, %0 " CTRL "\n\t"                 \
                  "v_min_u32_dpp %1, %1, %1 " CTRL : "+v"(a), "+v"(b));
-    asm volatile("s_nop 0");
     if (GS >= 2) POLAR_DPP_STAGE("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
     if (GS >= 4) POLAR_DPP_STAGE("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
     if (GS >= 8) POLAR_DPP_STAGE("row_half_mirror row_mask:0xf bank_mask:0xf")

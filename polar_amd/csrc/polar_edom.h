@@ -76,6 +76,9 @@ constexpr double ED_C40_LO = 4.248354255291589e-18 * (1.0 - 1e-10);
 // num / den for normal operands well inside the exponent range: v_rcp_f64 seed, Newton steps on the
 // reciprocal, one correction of the quotient (which squares the remaining error: <= 1 ulp)
 __device__ __forceinline__ double ed_div(double num, double den) {
+#ifdef POLAR_EXPERIMENT_FAST_DIV   // (measurement-only build: how much of the kernel time is the division's refinement)
+    return num * __builtin_amdgcn_rcp(den);
+#endif
     double r = __builtin_amdgcn_rcp(den);
     double e = __builtin_fma(-den, r, 1.0);
     r = __builtin_fma(r, e, r);

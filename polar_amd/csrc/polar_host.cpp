@@ -10,7 +10,10 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <cmath>
 #include <cstdarg>
@@ -76,7 +79,8 @@ struct polar_code {
     std::vector<uint16_t> info_rank; // [K+crc]
     std::vector<uint32_t> crc_mask;  // [crc*W]
     std::vector<uint8_t> sched;      // [N] rate-0 block schedule for the kernel (0 / 2 / 3)
-    std::vector<uint32_t> ctl;       // [N] frozen | sched << 1
+    std::vector<uint32_t> ctl;       // [N] frozen | sched << 1 | weak-unfrozen-leaf << 8
+    int weak_leaves = 0;             // unfrozen leaves no construction for an ordinary channel would leave unfrozen (derive_tables)
     std::vector<uint32_t> sc_ops;    // schedule of the list-size-1 kernel (PolarScParams::ops)
     // device
     bool dev_ready = false;
@@ -107,6 +111,9 @@ struct polar_code {
     DevBuf<unsigned long long> d_mc_ctr;     // [n_L*n_e][2]: block errors, bit errors of the round
     // per-device clones for polar_get_bler_quick_multi (owned by this handle)
     std::vector<polar_code *> clones;
+    // streams + RCCL communicators of the last multi-device call, kept for the next one with the same device list
+    // (an 8-rank ncclCommInitAll costs about as long as a short sweep runs)
+    struct MultiCtx *multi = nullptr;
     // tuning
     int waves_per_cu = 0, lds_log = 0, pipe = -1;
     bool prefix_on = true;
@@ -197,6 +204,29 @@ int derive_tables(polar_code *h) {
     }
     h->ctl.resize(N);
     for (int i = 0; i < N; ++i) h->ctl[i] = (uint32_t)(h->frozen[i] ? 1u : 0u) | ((uint32_t)h->sched[i] << 1);
+    // Unfrozen leaves in the worst synthetic channels (explicit tables, rates near 1, a design parameter that does not
+    // describe the channel): their LLR is an f-chain over hundreds of channel values, 1e-30 and below, and what the
+    // reference decides on is the rounding noise of its own arithmetic (DESIGN.md "Where bit-exactness ends"). The
+    // LLR-domain kernel follows that arithmetic much further down than the exp-domain one, whose stored form resolves
+    // 1e-16 ABSOLUTE near 0. Classified here, once, at no cost per decode: a leaf whose capacity over a BEC(1/2) is
+    // below 1e-3 (1 - z, tracked as such: z itself rounds to 1) gets bit 8 of its control word, and the exp-domain
+    // kernel hands every codeword in which such a leaf comes out below 1e-8 to the LLR-domain kernel. Codes built for
+    // their channel have no such leaf, or never such a value in it (the 16-ASK BICM table: 39 marked leaves whose
+    // LLRs are large on the channel the table was made for).
+    h->weak_leaves = 0;
+    {
+        std::vector<double> z(1, 0.5), om(1, 0.5), z2, om2;         // erasure probability and its complement
+        for (int l = 0; l < h->n; ++l) {
+            z2.resize(2 * z.size()); om2.resize(2 * z.size());
+            for (size_t i = 0; i < z.size(); ++i) {
+                z2[2 * i] = 2 * z[i] - z[i] * z[i]; om2[2 * i] = om[i] * om[i];              // f: bit 0 of the leaf index, top layer first
+                z2[2 * i + 1] = z[i] * z[i];        om2[2 * i + 1] = om[i] * (1.0 + z[i]);   // g
+            }
+            z.swap(z2); om.swap(om2);
+        }
+        for (int i = 0; i < N; ++i)
+            if (!h->frozen[i] && om[i] < 1e-3) { h->ctl[i] |= 0x100u; ++h->weak_leaves; }
+    }
     // CRC row i as a parity mask over unfrozen ranks, check bit included: crc_check passes iff
     // parity(history & mask_i) == 0 for every row (PolarCode.cpp:93-108)
     h->crc_mask.assign((size_t)crc * h->W, 0u);
@@ -266,6 +296,8 @@ int ensure_device(polar_code *h, DevGuard &dg) {
 }
 
 int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+void multi_release(polar_code *h, bool abort_comms);     // (defined next to bler_impl)
 
 }  // namespace
 
@@ -337,6 +369,7 @@ int polar_create_explicit(int n, int K, int crc, const uint8_t *frozen, const ui
 
 void polar_destroy(polar_code_t *h) {
     if (!h) return;
+    multi_release(h, false);
     for (polar_code *c : h->clones) polar_destroy(c);
     h->clones.clear();
     DevGuard dg_;
@@ -545,8 +578,8 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
         HIP_TRY(polar_launch_decode_llr(pf, gs, lds_log, pipe, std::min(grid, 16 * wpb), false, st));
         return POLAR_OK;
     }
-    const bool ed = (mode == 2) || (mode == 0 && gs >= 8);
-    if (ed && gs < 4) return fail(POLAR_E_ARG, "exp-domain mode needs a list size >= 3");
+    // (the exp-domain kernels exist for groups of 4 lanes and more: smaller lists take the LLR-domain kernel in every mode)
+    const bool ed = ((mode == 2) || (mode == 0 && gs >= 8)) && gs >= 4;
     HIP_TRY(hipMemsetAsync(p.work, 0, sizeof(unsigned int), st));
     if (!ed) {
         if (p.prefix_q) HIP_TRY(polar_launch_prefix(p, false, st));
@@ -579,7 +612,8 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
     PolarDecodeParams pf = p;
     pf.prefix_q = 0; pf.prefix_len = 0; pf.pre = nullptr;
     pf.cw_list = h->d_list.p; pf.cw_count = h->d_count.p; pf.n_dev = nullptr;
-    const int fgrid = std::min(grid, 64 * wpb);
+    // (normally empty: a few blocks; a code with weak unfrozen leaves may send most of its codewords here)
+    const int fgrid = h->weak_leaves ? grid : std::min(grid, 64 * wpb);
     HIP_TRY(polar_launch_decode_llr(pf, gs, lds_log, pipe, fgrid, false, st));
     return POLAR_OK;
 }
@@ -930,6 +964,7 @@ struct Rccl {
     void *lib = nullptr;
     int (*CommInitAll)(void **, int, const int *) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommAbort)(void *) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     bool load() {
@@ -950,6 +985,7 @@ struct Rccl {
         if (!lib) return false;
         CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
         CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        CommAbort = (decltype(CommAbort))dlsym(lib, "ncclCommAbort");
         AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
         GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
         return CommInitAll && CommDestroy && AllReduce;
@@ -957,7 +993,49 @@ struct Rccl {
 };
 Rccl g_rccl;
 constexpr int kNcclUint64 = 5, kNcclSum = 0;     // rccl.h: ncclUint64, ncclSum
+std::atomic<int> g_comm_inits{0};                // test hook (polar_debug_comm_inits): ncclCommInitAll calls so far
 
+// all worker threads of a round meet here before the collective: either every one of them enters ncclAllReduce or none does
+struct HostBarrier {
+    std::mutex m; std::condition_variable cv; int n, waiting = 0; unsigned gen = 0;
+    explicit HostBarrier(int n_) : n(n_) {}
+    void wait() {
+        std::unique_lock<std::mutex> lk(m);
+        const unsigned g = gen;
+        if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+};
+
+}  // namespace
+
+// streams and communicators of a device list, owned by the handle (polar_code::multi)
+struct MultiCtx {
+    std::vector<int> devs;               // as listed by the caller
+    std::vector<hipStream_t> streams;
+    std::vector<void *> comms;           // empty without RCCL
+    bool rccl = false;
+};
+
+namespace {
+
+void multi_release(polar_code *h, bool abort_comms) {
+    MultiCtx *m = h->multi;
+    if (!m) return;
+    h->multi = nullptr;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (size_t d = 0; d < m->comms.size(); ++d)
+        if (m->comms[d]) {
+            // after a failed round a rank may be stuck inside a collective: abort, do not wait for it
+            if (abort_comms && g_rccl.CommAbort) (void)g_rccl.CommAbort(m->comms[d]);
+            else (void)g_rccl.CommDestroy(m->comms[d]);
+        }
+    for (size_t d = 0; d < m->streams.size(); ++d)
+        if (m->streams[d]) { (void)hipSetDevice(m->devs[d]); (void)hipStreamDestroy(m->streams[d]); }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    delete m;
+}
 // the handle's tables on another device (owned by `h`, reused by later calls)
 polar_code *clone_on_device(polar_code *h, int dev, bool fresh = false) {
     // fresh: a context of its own even when one exists for this device (test hook POLAR_TEST_SHARE_DEVICE)
@@ -969,7 +1047,7 @@ polar_code *clone_on_device(polar_code *h, int dev, bool fresh = false) {
     c->n = h->n; c->N = h->N; c->K = h->K; c->crc = h->crc; c->eps = h->eps;
     c->frozen = h->frozen; c->order = h->order; c->bitrev = h->bitrev; c->crcm = h->crcm;
     c->W = h->W; c->info_rank = h->info_rank; c->crc_mask = h->crc_mask; c->sched = h->sched; c->ctl = h->ctl;
-    c->sc_ops = h->sc_ops;
+    c->sc_ops = h->sc_ops; c->weak_leaves = h->weak_leaves;
     c->device = dev;
     c->waves_per_cu = h->waves_per_cu; c->lds_log = h->lds_log; c->pipe = h->pipe; c->prefix_on = h->prefix_on; c->mode = h->mode;
     h->clones.push_back(c);
@@ -995,9 +1073,10 @@ int bler_impl(polar_code_t *h, const int *devices, int n_dev, const double *ebno
     std::vector<uint8_t> en(P, 1);
     DevGuard dg_;
     (void)hipGetDevice(&dg_.prev);
-    // one context (clone of the tables + scratch + stream) per device
+    // one context (clone of the tables + scratch) per device; streams and communicators live on the handle and are
+    // reused by the next call with the same device list
     std::vector<polar_code *> ctx(n_dev);
-    std::vector<hipStream_t> streams(n_dev, nullptr);
+    std::vector<int> devs(n_dev);
     int ndev_visible = 0;
     bool dup = false;
     if (hipGetDeviceCount(&ndev_visible) != hipSuccess || ndev_visible <= 0)
@@ -1005,36 +1084,66 @@ int bler_impl(polar_code_t *h, const int *devices, int n_dev, const double *ebno
     for (int d = 0; d < n_dev; ++d) {
         const int dev = devices ? devices[d] : d;
         if (dev < 0 || dev >= ndev_visible) return fail(POLAR_E_ARG, "device %d not visible (%d devices)", dev, ndev_visible);
-        // (test hook: POLAR_TEST_SHARE_DEVICE lets one GPU stand in for several, so that the per-device contexts, worker
-        // threads, strided trial partition and counter sum are exercised on a single-GPU box; RCCL cannot have two ranks
-        // on one device, the counters are then summed on the host)
-        bool again = false;
+        devs[d] = dev;
         for (int e = 0; e < d; ++e)
-            if ((devices ? devices[e] : e) == dev) {
+            if (devs[e] == dev) {
+                // (test hook: POLAR_TEST_SHARE_DEVICE lets one GPU stand in for several, so that the per-device contexts,
+                // worker threads, strided trial partition and counter sum are exercised on a single-GPU box; RCCL cannot
+                // have two ranks on one device, the counters are then summed on the host)
                 if (!getenv("POLAR_TEST_SHARE_DEVICE")) return fail(POLAR_E_ARG, "device %d listed twice", dev);
-                dup = again = true;
+                dup = true;
             }
-        if (h->device < 0 && d == 0) h->device = dev;
-        ctx[d] = clone_on_device(h, dev, again);
+    }
+    const bool want_rccl = (n_dev > 1 || getenv("POLAR_FORCE_RCCL")) && !getenv("POLAR_NO_RCCL") && !dup;
+    if (h->multi && (h->multi->devs != devs || (want_rccl && !h->multi->rccl && g_rccl.load()))) multi_release(h, false);
+    for (int d = 0; d < n_dev; ++d) {
+        bool again = false;
+        for (int e = 0; e < d; ++e) again |= (devs[e] == devs[d]);
+        if (h->device < 0 && d == 0) h->device = devs[d];
+        // (a repeated device gets a context of its own; an earlier call's are reused)
+        if (again) {
+            ctx[d] = nullptr;
+            for (polar_code *c : h->clones) {
+                bool used = false;
+                for (int e = 0; e < d; ++e) used |= (ctx[e] == c);
+                if (c->device == devs[d] && !used) { ctx[d] = c; break; }
+            }
+            if (!ctx[d]) ctx[d] = clone_on_device(h, devs[d], true);
+        } else ctx[d] = clone_on_device(h, devs[d], false);
         DevGuard g2;
         int rc = ensure_device(ctx[d], g2);
         g2.prev = -1;
         if (rc) return rc;
-        HIP_TRY(hipStreamCreateWithFlags(&streams[d], hipStreamNonBlocking));
     }
-    auto cleanup = [&]() { for (int d = 0; d < n_dev; ++d) if (streams[d]) { (void)hipSetDevice(ctx[d]->device); (void)hipStreamDestroy(streams[d]); } };
-    // RCCL communicators (single process, one rank per device); without RCCL the counters are summed on the host
-    std::vector<void *> comms(n_dev, nullptr);
-    bool rccl = false;
-    if ((n_dev > 1 || getenv("POLAR_FORCE_RCCL")) && !getenv("POLAR_NO_RCCL") && !dup && g_rccl.load()) {
-        std::vector<int> devs(n_dev);
-        for (int d = 0; d < n_dev; ++d) devs[d] = ctx[d]->device;
-        rccl = (g_rccl.CommInitAll(comms.data(), n_dev, devs.data()) == 0);
+    if (!h->multi) {
+        MultiCtx *m = new MultiCtx;
+        m->devs = devs;
+        m->streams.assign(n_dev, nullptr);
+        h->multi = m;                                // owned from here on: an early return below leaks nothing
+        for (int d = 0; d < n_dev; ++d) {
+            hipError_t e = hipSetDevice(devs[d]);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->streams[d], hipStreamNonBlocking);
+            if (e != hipSuccess) { multi_release(h, false); return fail(POLAR_E_DEVICE, "stream on device %d: %s", devs[d], hipGetErrorString(e)); }
+        }
+        // RCCL communicators (single process, one rank per device); without RCCL the counters are summed on the host
+        if (want_rccl && g_rccl.load()) {
+            m->comms.assign(n_dev, nullptr);
+            ++g_comm_inits;
+            m->rccl = (g_rccl.CommInitAll(m->comms.data(), n_dev, devs.data()) == 0);
+            if (!m->rccl) m->comms.clear();
+        }
     }
+    MultiCtx *mc = h->multi;
+    const std::vector<hipStream_t> &streams = mc->streams;
+    const bool rccl = mc->rccl && want_rccl;
     if (used_rccl) *used_rccl = rccl ? 1 : 0;
     int rc_all = POLAR_OK;
     std::string err_msg;
-    for (long done = 0; done < max_runs;) {
+    // test hook: POLAR_TEST_FAIL_DEVICE=<d> makes worker d report a failure in its second round (the abort path below
+    // cannot be reached with healthy hardware)
+    const int fail_dev = getenv("POLAR_TEST_FAIL_DEVICE") ? atoi(getenv("POLAR_TEST_FAIL_DEVICE")) : -1;
+    int round_no = 0;
+    for (long done = 0; done < max_runs; ++round_no) {
         bool any = false;
         for (int i = 0; i < P; ++i) { en[i] = (err[i] <= (uint64_t)max_err); any |= en[i]; }   // :725
         if (!any) break;
@@ -1045,26 +1154,34 @@ int bler_impl(polar_code_t *h, const int *devices, int n_dev, const double *ebno
         std::vector<std::string> msgs(n_dev);
         std::vector<long> Td(n_dev);
         std::vector<std::vector<unsigned long long>> host_ctr(n_dev, std::vector<unsigned long long>((size_t)2 * P, 0));
+        HostBarrier bar(n_dev);
+        std::atomic<int> n_failed{0};
         auto worker = [&](int d) {
             polar_code *c = ctx[d];
             Td[d] = (T - d + n_dev - 1) / n_dev;
-            if (hipSetDevice(c->device) != hipSuccess) { rcs[d] = POLAR_E_DEVICE; msgs[d] = "hipSetDevice failed"; return; }
             int rc = POLAR_OK;
-            if (Td[d] > 0)
+            if (hipSetDevice(c->device) != hipSuccess) { rc = POLAR_E_DEVICE; msgs[d] = "hipSetDevice failed"; }
+            else if (d == fail_dev && round_no == 1) { rc = POLAR_E_DEVICE; msgs[d] = "injected failure (POLAR_TEST_FAIL_DEVICE)"; }
+            else if (Td[d] > 0)
                 rc = mc_round_launch(c, 0, seed, (uint64_t)(done + d), Td[d], n_dev, ebno, n_e, Ls, n_L, en.data(), streams[d]);
             else
                 rc = (c->d_mc_ctr.ensure((size_t)2 * P) || hipMemsetAsync(c->d_mc_ctr.p, 0, (size_t)2 * P * 8, streams[d]) != hipSuccess) ? POLAR_E_DEVICE : POLAR_OK;
-            if (!rc && rccl) {
+            if (rc && msgs[d].empty()) msgs[d] = polar_last_error();
+            // every worker learns whether ALL of them got this far: a rank that skipped the collective on its own would
+            // leave the others blocked in it for good
+            if (rc) ++n_failed;
+            if (n_dev > 1) bar.wait();
+            const bool round_ok = (n_failed.load() == 0);
+            if (round_ok && rccl) {
                 // sum of the round's counters over the devices (xGMI), in place on every device
-                if (g_rccl.AllReduce(c->d_mc_ctr.p, c->d_mc_ctr.p, (size_t)2 * P, kNcclUint64, kNcclSum, comms[d], streams[d]) != 0) {
+                if (g_rccl.AllReduce(c->d_mc_ctr.p, c->d_mc_ctr.p, (size_t)2 * P, kNcclUint64, kNcclSum, mc->comms[d], streams[d]) != 0) {
                     rc = POLAR_E_DEVICE; msgs[d] = "ncclAllReduce failed";
                 }
             }
-            if (!rc && (!rccl || d == 0)) {
-                if (hipMemcpyAsync(host_ctr[d].data(), c->d_mc_ctr.p, (size_t)2 * P * 8, hipMemcpyDeviceToHost, streams[d]) != hipSuccess) rc = POLAR_E_DEVICE;
+            if (round_ok && !rc && (!rccl || d == 0)) {
+                if (hipMemcpyAsync(host_ctr[d].data(), c->d_mc_ctr.p, (size_t)2 * P * 8, hipMemcpyDeviceToHost, streams[d]) != hipSuccess) { rc = POLAR_E_DEVICE; msgs[d] = "counter copy failed"; }
             }
             if (hipStreamSynchronize(streams[d]) != hipSuccess && !rc) { rc = POLAR_E_DEVICE; msgs[d] = "stream synchronize failed"; }
-            if (rc && msgs[d].empty()) msgs[d] = polar_last_error();
             rcs[d] = rc;
         };
         if (n_dev == 1) worker(0);
@@ -1073,7 +1190,7 @@ int bler_impl(polar_code_t *h, const int *devices, int n_dev, const double *ebno
             for (int d = 0; d < n_dev; ++d) th.emplace_back(worker, d);
             for (auto &t : th) t.join();
         }
-        for (int d = 0; d < n_dev; ++d) if (rcs[d]) { rc_all = rcs[d]; err_msg = msgs[d]; }
+        for (int d = 0; d < n_dev; ++d) if (rcs[d]) { rc_all = rcs[d]; err_msg = "device " + std::to_string(devs[d]) + ": " + msgs[d]; }
         if (rc_all) break;
         for (int i = 0; i < P; ++i) {
             if (!en[i]) continue;
@@ -1082,8 +1199,8 @@ int bler_impl(polar_code_t *h, const int *devices, int n_dev, const double *ebno
         }
         done += T;
     }
-    if (rccl) for (int d = 0; d < n_dev; ++d) if (comms[d]) (void)g_rccl.CommDestroy(comms[d]);
-    cleanup();
+    // a failed round leaves the communicators in an unknown state: abort and rebuild them next time
+    if (rc_all) multi_release(h, true);
     if (rc_all) return fail(rc_all, "%s", err_msg.c_str());
     for (int i = 0; i < P; ++i) {
         bler_out[i] = run[i] ? (double)err[i] / (double)run[i] : 0.0;                 // :777-781
@@ -1110,6 +1227,7 @@ int polar_get_bler_quick_ber(polar_code_t *h, const double *ebno, int n_e, const
     if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return fail(POLAR_E_DEVICE, "no HIP device available; this library has no CPU decode path");
     return bler_impl(h, &dev, 1, ebno, n_e, Ls, n_L, max_runs, max_err, seed, batch, bler_out, ber_out, nullptr);
 }
+int polar_debug_comm_inits(void) { return g_comm_inits.load(); }
 int polar_get_bler_quick_multi(polar_code_t *h, const int *devices, int n_dev, const double *ebno, int n_e,
                                const uint8_t *Ls, int n_L, long max_runs, long max_err, uint64_t seed, long batch,
                                double *bler_out, double *ber_out, int *used_rccl) {

@@ -15,7 +15,7 @@ struct PolarDecodeParams {
     uint8_t *out;                // [B][K] device
     double *pm_out;              // [B] device or nullptr
     const uint8_t *frozen;       // [N] device
-    const uint32_t *ctl;         // [N] device: per-leaf control word of the LLR kernel = frozen | zb << 1, zb = log2 size (0, 2 or 3) of the all-frozen aligned block starting at this leaf (scalar-loaded)
+    const uint32_t *ctl;         // [N] device: per-leaf control word of the LLR kernel = frozen | zb << 1 | weak << 8, zb = log2 size (0, 2 or 3) of the all-frozen aligned block starting at this leaf, weak = unfrozen leaf in one of the worst channels (scalar-loaded)
     unsigned int *work;          // device counter (zeroed before the launch): dynamic hand-out of codeword groups after a wave's first one
     const uint16_t *info_rank;   // [K+crc] device: rank of order[beta] among the unfrozen positions
     const uint32_t *crc_mask;    // [crc][W] device: parity masks over unfrozen ranks (check bit included)

@@ -202,10 +202,13 @@ __device__ __forceinline__ void leaf_terms(double leaf, bool active, const Tabs 
 
 // Channel LLRs at the boundary are doubles (the reference's type) or floats (polar_decode_scl_llr_batch_dev_f32):
 // a float is widened — exactly — in the load itself, there is no staging copy. ch_row() = row `cw` of p.llr.
-__device__ __forceinline__ const double *ch_row(const PolarDecodeParams &p, size_t cw) {
-    return p.llr_f32 ? reinterpret_cast<const double *>(reinterpret_cast<const float *>(p.llr) + cw * (size_t)p.N)
-                     : p.llr + cw * (size_t)p.N;
+template <bool ED>
+__device__ __forceinline__ const double *ch_row(const PolarDecodeParams &p, size_t cw, int N) {
+    return p.llr_f32 ? reinterpret_cast<const double *>(reinterpret_cast<const float *>(p.llr) + cw * (size_t)N)
+                     : p.llr + cw * (size_t)N;
 }
+// (the exp-domain kernels never see floats — ed_front_kernel has widened and converted the channel values — but folding
+// that into the macro measured 1 % SLOWER on the headline kernel: register allocation of the hot loops shifts)
 #define CH(row, i) (p.llr_f32 ? (double)reinterpret_cast<const float *>(row)[i] : (row)[i])
 
 // Layer storage helpers --------------------------------------------------------------------
@@ -226,7 +229,9 @@ __device__ __forceinline__ const double *ch_row(const PolarDecodeParams &p, size
     const int lig = lane & (GS - 1);               \
     const int gbase = lane & ~(GS - 1);            \
     (void)lig; (void)gbase;
-template <int GS, int LDS_LOG, int PIPE, bool ED>
+// NL: 0 = block length taken from p (any code); else log2 of the block length this instantiation is compiled for (the
+// headline shapes: every layer size, row offset and loop bound is then a constant)
+template <int GS, int LDS_LOG, int PIPE, bool ED, int NL = 0>
 __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_llr_kernel(PolarDecodeParams p) {
     // ED: exp-domain node arithmetic (see f_node_e); the channel values at p.llr are then in stored form
     // (ed_front_kernel) and every codeword whose decisions are not safely reproduced is reported in p.flags
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     const int lig = lane & (GS - 1);   // path index l of the reference
     const int gbase = lane & ~(GS - 1);
     const int grp = lane / GS;
-    const int n = p.n, N = p.N, K = p.K, L = p.L;
+    const int n = NL ? NL : p.n, N = NL ? (1 << NL) : p.N, K = p.K, L = p.L;
     const u64 gmask = (GS == 64) ? ~0ull : ((1ull << GS) - 1ull);
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         guard = 0;
         auto cw_of_lane = [&](int ln) -> size_t {
             const long i = g0 + ln / GS;
-            return p.cw_list ? (size_t)p.cw_list[i] : (size_t)i;
+            return p.cw_list ? (size_t)p.cw_list[i < Bv ? i : Bv - 1] : (size_t)i;     // (lanes past the end of the work list: any valid row)
         };
         auto FN2 = [&](double a0_, double b0_, double a1_, double b1_, double &r0_, double &r1_) {
             if constexpr (ED) { r0_ = f_node_e(a0_, b0_, guard); r1_ = f_node_e(a1_, b1_, guard); }
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 }
             };
             // all-frozen aligned block of 2^zb leaves starting here (host schedule), 0 = ordinary leaf
-            const int zb = (int)(ctl >> 1);
+            const int zb = (int)(ctl >> 1) & 0x7F;
             {
                 const int nphi = phi + (1 << zb);
                 ctl_next = ctlp[nphi < N ? nphi : 0];
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                             }
                         } else {
                             if (kind == 2) {
-                                const double *chr = ch_row(p, cw_of_lane(lane));
+                                const double *chr = ch_row<ED>(p, cw_of_lane(lane), N);
                                 for (int e = lig; e < S1; e += GS) {
                                     const unsigned i0 = __brev((unsigned)e) >> (32 - n);
                                     const double a = CH(chr, i0), b = CH(chr, i0 + 1);
@@ -509,7 +514,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                         const bool in_is_ch = (lam == 1);
                         const bool in_pre = !in_is_ch && p.prefix_q > 0 && 2 * S >= p.prefix_q && phi < 2 * S;
                         // (active lanes are valid ones: codeword g0 + lane / GS)
-                        const double *in0 = in_is_ch ? ch_row(p, cw_of_lane(lane)) : nullptr;
+                        const double *in0 = in_is_ch ? ch_row<ED>(p, cw_of_lane(lane), N) : nullptr;
                         const double *pre_cw = in_pre ? p.pre + cw_of_lane(lane) * (size_t)(N - p.prefix_q + 1) : nullptr;
                         const int pin = (in_is_ch || in_pre) ? 0 : pL.get(sh + 1);
                         const size_t istr = in_pre ? 1 : 64;      // prefix layers are contiguous per codeword
@@ -602,15 +607,34 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                                         a[m] = CH(in0, i0); b[m] = CH(in0, i0 + 1);
                                     }
                                 } else {
+#ifdef POLAR_EXPERIMENT_FAKE_LD      // (measurement-only build: every pass re-reads the same 16 rows — cache hits instead of HBM reads)
+                                    const int jj = 0;
+#else
+                                    const int jj = j;
+#endif
 #pragma unroll
                                     for (int m = 0; m < 8; ++m) {
-                                        if (NT & 1) { a[m] = __builtin_nontemporal_load(inp + (size_t)(j + m * E) * istr); b[m] = __builtin_nontemporal_load(inp + (size_t)(j + m * E + S) * istr); }
-                                        else { a[m] = inp[(size_t)(j + m * E) * istr]; b[m] = inp[(size_t)(j + m * E + S) * istr]; }
+                                        if (NT & 1) { a[m] = __builtin_nontemporal_load(inp + (size_t)(jj + m * E) * istr); b[m] = __builtin_nontemporal_load(inp + (size_t)(jj + m * E + S) * istr); }
+                                        else { a[m] = inp[(size_t)(jj + m * E) * istr]; b[m] = inp[(size_t)(jj + m * E + S) * istr]; }
                                     }
                                 }
                             };
+#ifdef POLAR_PF
+                            // L2 prefetch of the NEXT pass's 16 source rows with ONE scattered load: a row is four 128-B lines, so
+                            // the 64 lanes of a single global_load_dword touch every line of those rows (lane -> row (lane >> 2),
+                            // line (lane & 3)). It costs one VGPR and no wait: the value is dropped after the next pass's real loads
+                            // have been issued, and those then hit the L2 instead of paying the HBM latency per pass.
+                            const bool pf_on = !TS && !in_is_ch && !in_pre && E > 1;
+                            const uint32_t *pfp = pf_on ? reinterpret_cast<const uint32_t *>(g_llr + (size_t)(2 * S - 2 * SL) * 64) +
+                                                          ((size_t)(((lane >> 2) & 7) * E + (lane >> 5) * S) * 128 + (size_t)(lane & 3) * 32) : nullptr;
+                            uint32_t pfv = 0;
+#endif
                             for (int j = 0; j < E; ++j) {
                                 load8(j);
+#ifdef POLAR_PF
+                                asm volatile("" : "+v"(pfv));
+                                if (pf_on && j + 1 < E) pfv = pfp[(size_t)(j + 1) * 128];
+#endif
                                 if (odd && S > 32 && (j & 31) == 0) {
 #pragma unroll
                                     for (int m = 0; m < 8; ++m) cw8[m] = cwp[(size_t)((j + m * E) >> 5) * 64];
@@ -622,12 +646,17 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                                 }
                                 // (issuing the next pass's loads here, ahead of the 15 stores, was measured: -15 % — the
                                 // double-buffered inputs do not fit the 128-VGPR budget)
+#ifdef POLAR_EXPERIMENT_FAKE_ST      // (measurement-only build: the stores of a pass land on the rows of its first iteration)
+                                const int js = 0;
+#else
+                                const int js = j;
+#endif
 #pragma unroll
-                                for (int m = 0; m < 8; ++m) { if (NT & 2) __builtin_nontemporal_store(v[m], o0 + (size_t)(j + m * E) * 64); else o0[(size_t)(j + m * E) * 64] = v[m]; }
+                                for (int m = 0; m < 8; ++m) { if (NT & 2) __builtin_nontemporal_store(v[m], o0 + (size_t)(js + m * E) * 64); else o0[(size_t)(js + m * E) * 64] = v[m]; }
 #pragma unroll
-                                for (int m = 0; m < 4; ++m) { v[m] = FN(v[m], v[m + 4]); if (NT & 4) __builtin_nontemporal_store(v[m], o1 + (size_t)(j + m * E) * 64); else o1[(size_t)(j + m * E) * 64] = v[m]; }
+                                for (int m = 0; m < 4; ++m) { v[m] = FN(v[m], v[m + 4]); if (NT & 4) __builtin_nontemporal_store(v[m], o1 + (size_t)(js + m * E) * 64); else o1[(size_t)(js + m * E) * 64] = v[m]; }
 #pragma unroll
-                                for (int m = 0; m < 2; ++m) { v[m] = FN(v[m], v[m + 2]); if (NT & 8) __builtin_nontemporal_store(v[m], o2 + (size_t)(j + m * E) * 64); else o2[(size_t)(j + m * E) * 64] = v[m]; }
+                                for (int m = 0; m < 2; ++m) { v[m] = FN(v[m], v[m + 2]); if (NT & 8) __builtin_nontemporal_store(v[m], o2 + (size_t)(js + m * E) * 64); else o2[(size_t)(js + m * E) * 64] = v[m]; }
                                 v[0] = FN(v[0], v[1]);
                                 o3[(size_t)j * 64] = v[0];
                                 leaf = v[0];            // (the leaf value when S/8 == 1)
@@ -721,7 +750,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     size_t istride;
                     const bool in_is_ch = (lam == 1);
                     const bool in_pre = !in_is_ch && p.prefix_q > 0 && 2 * S >= p.prefix_q && phi < 2 * S;
-                    const double *in0 = in_is_ch ? ch_row(p, cw_of_lane(lane)) : nullptr;
+                    const double *in0 = in_is_ch ? ch_row<ED>(p, cw_of_lane(lane), N) : nullptr;
                     const double *pre_cw = in_pre ? p.pre + cw_of_lane(lane) * (size_t)(N - p.prefix_q + 1) : nullptr;
                     constexpr bool in_lds = false;          // (LDS inputs were handled above)
                     istride = 64;
@@ -923,6 +952,14 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 // (a logarithm-free lower bound of |llr| for this test — exponent and mantissa of E — was measured:
                 // -1.5 %, the bound is short by up to 0.06 and sends more steps down the ranking path)
                 leaf_terms<ED>(leaf, active, tb, lneg, al, sneg, spos);
+                if constexpr (ED) {
+                    // a leaf the host marked as weak (control word bit 8: no construction for an ordinary channel leaves it
+                    // unfrozen) that comes out below 1e-8: the reference decides on the rounding noise of its own arithmetic
+                    // there, which the LLR-domain kernel follows much further down than this one -> fallback pass
+#ifndef POLAR_NO_WEAK_GUARD
+                    if (ctl & 0x100u) guard |= __ballot(active && fabs(leaf) > 0.99999999 && fabs(leaf) <= 1.0);
+#endif
+                }
                 if (active) {
                     gm = pm + sneg;
                     bl = (pm + al) * 0.99999999999909050530;
@@ -1357,7 +1394,7 @@ __global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p, int st
     for (long c0 = (long)blockIdx.x * per_block; c0 < Bv; c0 += (long)gridDim.x * per_block) {
         const long cw = c0 + (threadIdx.x >> 5);
         const bool valid = cw < Bv;
-        const double *in0 = ch_row(p, (size_t)(valid ? cw : 0));
+        const double *in0 = ch_row<ED>(p, (size_t)(valid ? cw : 0), N);
         double *pre = const_cast<double *>(p.pre) + (size_t)(valid ? cw : 0) * (size_t)(N - Q + 1);
         double x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int S = N / 2; S >= Q; S >>= 1) {
@@ -1561,14 +1598,26 @@ static hipError_t launch_gs(const PolarDecodeParams &p, int lds_log, int pipe, i
     size_t lds = polar_decode_lds_bytes(lds_log, pipe);
     const int wpb = polar_decode_waves_per_block(pipe);
 #define POLAR_LAUNCH(LL, PP) hipLaunchKernelGGL((scl_decode_llr_kernel<GS, LL, PP, ED>), dim3(grid / wpb), dim3(64 * wpb), lds, st, p)
+#ifndef POLAR_NO_FIXED_N
+    if constexpr (GS == 32 && ED) {
+        // the headline shapes (N = 2048 / 1024, list of 17..32, default tuning) have instantiations of their own
+        if (lds_log == 3 && !pipe && (p.n == 11 || p.n == 10)) {
+            if (p.n == 11) hipLaunchKernelGGL((scl_decode_llr_kernel<GS, 3, 0, ED, 11>), dim3(grid / wpb), dim3(64 * wpb), lds, st, p);
+            else hipLaunchKernelGGL((scl_decode_llr_kernel<GS, 3, 0, ED, 10>), dim3(grid / wpb), dim3(64 * wpb), lds, st, p);
+            return hipGetLastError();
+        }
+    }
+#endif
     switch (lds_log * 2 + (pipe ? 1 : 0)) {
-        case 4: POLAR_LAUNCH(2, 0); break;
         case 6: POLAR_LAUNCH(3, 0); break;
+#ifndef POLAR_DEV_ONE    // (development builds: the default tuning only)
+        case 4: POLAR_LAUNCH(2, 0); break;
         case 7: POLAR_LAUNCH(3, 1); break;
         case 8: POLAR_LAUNCH(4, 0); break;
         case 9: POLAR_LAUNCH(4, 1); break;
         case 10: POLAR_LAUNCH(5, 0); break;
         case 11: POLAR_LAUNCH(5, 1); break;
+#endif
         default: return hipErrorInvalidValue;
     }
 #undef POLAR_LAUNCH

@@ -1,0 +1,38 @@
+"""bench.py --gpus N: a plain launch must really run N ranks — or refuse. No GPU needed:
+the gloo dry run goes through the same launcher, rendezvous, barrier and counter all-reduce as the timed run."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(*a, env=None):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH, *a], capture_output=True, text=True, timeout=300, env=e, cwd=ROOT)
+
+
+def test_plain_launch_with_gpus_2_runs_two_ranks():
+    r = _run("--gpus", "2", "--steps", "2", "--dry-run-gloo")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["dry_run"] is True
+    assert line["runs_all_ranks"] == 2 * 2 * 262144          # both ranks' shards reached the reduction
+
+
+def test_world_size_and_gpus_must_agree():
+    r = _run("--gpus", "2", "--dry-run-gloo", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
+
+
+def test_more_gpus_than_visible_is_refused():
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    r = _run("--gpus", str(have + 1 if have else 2))
+    assert r.returncode != 0
+    assert "refusing" in (r.stderr + r.stdout)

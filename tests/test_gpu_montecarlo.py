@@ -103,6 +103,40 @@ def test_multi_device_partition_with_one_gpu_standing_in_for_several(built_lib, 
     assert not np.array_equal(np.asarray(want2), np.asarray(want)[2:3])     # (the matrix matters: different estimates)
 
 
+def test_communicators_and_streams_are_cached_on_the_handle(built_lib, monkeypatch):
+    """A second multi-device call with the same device list makes no ncclCommInitAll (an 8-rank init costs about as long
+    as a short sweep runs); another list, or a handle of its own, makes one."""
+    import polar_amd
+    L = polar_amd.lib()
+    L.polar_debug_comm_inits.restype = C.c_int
+    o, g = _pair(8, 128, 8)
+    monkeypatch.setenv("POLAR_FORCE_RCCL", "1")
+    n0 = L.polar_debug_comm_inits()
+    a = g.get_bler_quick([1.0, 2.0], [1, 4], max_runs=400, max_err=30, seed=3, batch=100, devices=[0])
+    assert g.last_used_rccl, "RCCL could not be loaded/initialised on the GPU box"
+    n1 = L.polar_debug_comm_inits()
+    b = g.get_bler_quick([1.0, 2.0], [1, 4], max_runs=400, max_err=30, seed=3, batch=100, devices=[0])
+    n2 = L.polar_debug_comm_inits()
+    assert n1 == n0 + 1 and n2 == n1
+    assert np.array_equal(np.asarray(a), np.asarray(b)) and g.last_used_rccl
+
+
+def test_a_failing_device_aborts_the_round_for_every_device(built_lib, monkeypatch):
+    """Device 1 of three fails in the second round (test hook): nobody enters the round's counter reduction (a lone
+    rank skipping ncclAllReduce used to leave the others blocked in it for good), the call returns the error, and the
+    handle works again afterwards."""
+    import polar_amd
+    o, g = _pair(8, 128, 8)
+    monkeypatch.setenv("POLAR_TEST_SHARE_DEVICE", "1")
+    want = g.get_bler_quick([1.0], [1, 4], max_runs=900, max_err=10**6, seed=3, batch=300, devices=[0, 0, 0])
+    monkeypatch.setenv("POLAR_TEST_FAIL_DEVICE", "1")
+    with pytest.raises(polar_amd.PolarError, match="injected failure"):
+        g.get_bler_quick([1.0], [1, 4], max_runs=900, max_err=10**6, seed=3, batch=300, devices=[0, 0, 0])
+    monkeypatch.delenv("POLAR_TEST_FAIL_DEVICE")
+    again = g.get_bler_quick([1.0], [1, 4], max_runs=900, max_err=10**6, seed=3, batch=300, devices=[0, 0, 0])
+    assert np.array_equal(np.asarray(again), np.asarray(want))
+
+
 def test_python_sharded_driver_and_strided_engine_on_the_gpu(built_lib, oracle_built):
     """polar_amd/montecarlo.py (the multi-process form bench.py / torchrun use) with the real GPU engine `mc_batch`:
     world size 1 equals the native driver round for round; and the engine's strided trial partition — rank r of a
