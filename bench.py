@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--lds-log", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="codewords for the CPU baseline (-1 = auto, 0 = skip)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short timings of BASELINE.json configs 1, 2, 3, 5")
+    ap.add_argument("--only-config", default="", help="run ONE of the other configurations (" + ", ".join(OTHER_CONFIGS) + ") and print its record: the command tools/profile_configs.sh profiles")
     ap.add_argument("--dry-run-gloo", action="store_true",
                     help="launcher / rendezvous / counter all-reduce only, on CPU over gloo: no kernel runs, the line carries "
                          "\"dry_run\": true and no throughput (tests/test_bench_launcher.py)")
@@ -81,6 +82,12 @@ def main():
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
+    if args.only_config:
+        from polar_amd import build
+        if not os.environ.get("POLAR_AMD_LIB"):
+            build.build()
+        print(json.dumps(run_config(args.only_config, args, torch.device("cuda", local_rank), steps=args.steps, with_cpu=False)), flush=True)
+        return
     dist = None
     if world > 1 or os.environ.get("BENCH_FORCE_DIST"):
         import torch.distributed as dist_mod
@@ -192,6 +199,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_profile_lib_sha256": prof.get("lib_sha256"),
             "kernel_ms_avg": kern_avg_s * 1e3,
             "algorithmic_bytes_per_codeword": alg_bytes_per_cw,
             "algorithmic_bytes_per_launch": B * alg_bytes_per_cw,
@@ -266,7 +274,8 @@ def traffic_from_profile(args, B):
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         c = t["config"]
-        if (c["n"], c["K"], c["crc"], c["L"], c["batch"]) == (args.n, args.K, args.crc, args.L, B):
+        # a profile counts only for the library it was taken with: a kernel change without a re-profile reports null
+        if (c["n"], c["K"], c["crc"], c["L"], c["batch"]) == (args.n, args.K, args.crc, args.L, B) and t.get("lib_sha256") == lib_sha256():
             return t["traffic_bytes_per_launch"], t
     except Exception:
         pass
@@ -337,37 +346,121 @@ def cpu_baseline(args, code, llr, out):
     }
 
 
-def other_configs(args, dev):
-    """Short kernel+count timings of the other BASELINE.json configurations in the same run (same library, same
-    box): not the headline metric, three steps each on device-generated trials."""
+def lib_sha256():
+    import hashlib
+    import polar_amd
+    path = os.environ.get("POLAR_AMD_LIB") or os.path.join(ROOT, "polar_amd", "libpolar_amd.so")
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def profile_entry(name):
+    """Counter traffic of configuration `name` from the committed rocprofv3 PMC passes (profiles/traffic_configs.json,
+    tools/profile_configs.sh) — only when they were taken with THIS library (sha256 of libpolar_amd.so); a profile of
+    another build is refused (null), never reported as if it were live."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic_configs.json")))
+        if t.get("lib_sha256") == lib_sha256():
+            return t["configs"].get(name)
+    except Exception:
+        pass
+    return None
+
+
+OTHER_CONFIGS = {
+    # name: (n, K, crc, L, batch, axis value [Eb/N0 dB, or SNR dB for 16-ASK], constellation, dominant kernel, CPU sample)
+    "config1": (9, 256, 0, 1, 262144, 2.0, "bpsk", "sc8_decode_kernel", 4096),
+    "config2": (11, 1024, 0, 1, 65536, 2.0, "bpsk", "sc8_decode_kernel", 4096),        # SURVEY §8d: 4 096-codeword CPU prefix
+    "config2_b262144": (11, 1024, 0, 1, 262144, 2.0, "bpsk", "sc8_decode_kernel", 0),
+    "config3": (11, 1024, 16, 4, 65536, 2.0, "bpsk", "scl_decode_llr_kernel<4, 3, 0, false>", 2048),
+    "config5": (10, 512, 0, 8, 65536, 13.0, "ask16-gray", "scl_decode_llr_kernel<8, 3, 0, true>", 2048),
+}
+
+
+def make_config(name):
+    """The code and the workload description of one BASELINE.json configuration. config 5 is the reference's OWN code:
+    the Monte-Carlo construction table it ships for 16-ASK Gray BICM at 13 dB (a committed data fixture,
+    tests/golden/polar_golden.npz), decoded on 16-ASK BICM LLRs at the centre of its SNR grid."""
     import ctypes as C
     import polar_amd
-    outs = []
-    for name, n, K, crc, L, B, ebno in (("config 1 code (N=512 K=256 L=1)", 9, 256, 0, 1, 262144, 2.0),
-                                        ("config 2 (N=2048 K=1024 L=1 SC)", 11, 1024, 0, 1, 65536, 2.0),
-                                        ("config 2, batch 262144", 11, 1024, 0, 1, 262144, 2.0),
-                                        ("config 3 (N=2048 K=1024 crc16 L=4)", 11, 1024, 16, 4, 65536, 2.0),
-                                        ("config 5 code (N=1024 K=512 L=8)", 10, 512, 0, 8, 65536, 2.0)):
+    n, K, crc, L, B, axis, const, kern, cpu_n = OTHER_CONFIGS[name]
+    C.CDLL(None).srand(C.c_uint(1))
+    if const == "bpsk":
+        code = polar_amd.PolarCode(n, K, 0.32, crc)
+    else:
+        g = np.load(os.path.join(ROOT, "tests", "golden", "polar_golden.npz"))
+        code = polar_amd.PolarCode.from_counts(g["cfg5_n10_k512_ask16/counts"], K, crc)
+    return code
+
+
+def run_config(name, args, dev, steps=3, with_cpu=True):
+    import ctypes as C
+    import oracle_lib
+    n, K, crc, L, B, axis, const, kern, cpu_n = OTHER_CONFIGS[name]
+    code = make_config(name)
+    Nn = 1 << n
+    llr = torch.empty((B, Nn), dtype=torch.float64, device=dev)
+    sent = torch.empty((B, K), dtype=torch.uint8, device=dev)
+    out = torch.empty((B, K), dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+    if const == "bpsk":
+        code.synth_llr_dev(args.seed, 0, B, code.snr_sqrt_linear(axis), llr.data_ptr(), sent.data_ptr())
+    else:
+        code.synth_bicm_llr_dev(const, args.seed, 0, B, axis, llr.data_ptr(), sent.data_ptr())
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b_ in ev:
+        a.record(); b_.record()
+    code.decode_scl_llr_dev(llr.data_ptr(), B, L, out.data_ptr())                 # warm-up (allocations)
+    code.count_errors_dev(out.data_ptr(), sent.data_ptr(), B, cnt.data_ptr())
+    cnt.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        code.decode_scl_llr_dev(llr.data_ptr(), B, L, out.data_ptr(), ev_start=ev[i][0].cuda_event, ev_stop=ev[i][1].cuda_event)
+        code.count_errors_dev(out.data_ptr(), sent.data_ptr(), B, cnt.data_ptr())
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    kern_s = sum(a.elapsed_time(b_) for a, b_ in ev) / steps / 1e3
+    alg = Nn * 8 + K
+    achieved = B * alg / kern_s / 1e9
+    prof = profile_entry(name)
+    traffic = prof["traffic_bytes_per_launch"] if prof else None
+    res = {"config": name, "workload": f"N={Nn} K={K} crc={crc} L={L} {const} " + (f"Eb/N0={axis} dB" if const == "bpsk" else f"SNR={axis} dB (BICM)") + f", batch {B}",
+           "batch": B, "value": B / dt, "unit": "codewords/s", "ms_per_step": dt * 1e3,
+           "block_errors_per_step": int(cnt[0].item()) // steps,
+           "roofline": {"bound": "hbm", "kernel": kern, "kernel_ms_avg": kern_s * 1e3, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_codeword": alg,
+                        "traffic": traffic,
+                        "traffic_over_algorithmic": (traffic / (B * alg)) if traffic else None,
+                        "traffic_rate_GBps": (traffic / kern_s / 1e9) if traffic else None,
+                        "kernel_ms_in_profile": prof.get("kernel_avg_ns", 0) / 1e6 if prof else None}}
+    if with_cpu and cpu_n:
+        # the CPU side on a bounded prefix of the SAME batch, single thread: the unmodified reference build when it travelled
+        # with the snapshot (kind "reference"), else the C restatement (kind "port"); and the GPU result checked against it
+        kind = "reference" if oracle_lib.have_reference() else "port"
         C.CDLL(None).srand(C.c_uint(1))
-        c = polar_amd.PolarCode(n, K, 0.32, crc)
-        Nn = 1 << n
-        llr = torch.empty((B, Nn), dtype=torch.float64, device=dev)
-        sent = torch.empty((B, K), dtype=torch.uint8, device=dev)
-        out = torch.empty((B, K), dtype=torch.uint8, device=dev)
-        cnt = torch.zeros(2, dtype=torch.int64, device=dev)
-        c.synth_llr_dev(args.seed, 0, B, c.snr_sqrt_linear(ebno), llr.data_ptr(), sent.data_ptr())
-        for it in range(4):
-            if it == 1:
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-            c.decode_scl_llr_dev(llr.data_ptr(), B, L, out.data_ptr())
-            c.count_errors_dev(out.data_ptr(), sent.data_ptr(), B, cnt.data_ptr())
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 3
-        outs.append({"config": name, "batch": B, "ebno_db": ebno, "value": B / dt, "unit": "codewords/s",
-                     "ms_per_step": dt * 1e3, "block_errors_per_step": int(cnt[0].item()) // 4})
-        del llr, sent, out
-    return outs
+        cpu = (oracle_lib.Reference if kind == "reference" else oracle_lib.Oracle)(n, K, 0.32, crc, srand=1)
+        if const != "bpsk":
+            cpu.set_tables(code.frozen_bits, code.channel_order_descending)
+        h = llr[:cpu_n].cpu().numpy()
+        t = time.perf_counter()
+        ref_out = cpu.decode_scl_llr(h, L)
+        tc = time.perf_counter() - t
+        res["cpu_baseline"] = {"value": cpu_n / tc, "unit": "codewords/s", "cores": 1, "kind": kind,
+                               "sample": f"first {cpu_n} codewords of the batch, decode_scl_llr only, single thread",
+                               "gpu_vs_cpu_mismatching_codewords": int((ref_out != out[:cpu_n].cpu().numpy()).any(axis=1).sum())}
+    del llr, sent, out
+    return res
+
+
+def other_configs(args, dev):
+    """The other BASELINE.json configurations in the same run (same library, same box), each on ITS OWN workload: decode +
+    count, three steps, dominant-kernel time from HIP events, roofline, counter traffic from the committed per-config
+    profile (refused unless taken with this very library), a reference CPU sample and the GPU-vs-CPU mismatch count."""
+    return [run_config(name, args, dev) for name in OTHER_CONFIGS]
 
 
 if __name__ == "__main__":

@@ -335,7 +335,7 @@ class PolarCode:
                                     _p(enabled, _u8p), _p(err, _u64p), _p(run, _u64p)))
 
     def synth_bicm_llr_dev(self, constellation, seed, trial0, B, snr_db, llr_ptr, info_ptr=0, stream=None):
-        _check(lib().polar_synth_bicm_llr_dev(self._h, C.c_int(constellation), C.c_uint64(seed), C.c_uint64(trial0),
+        _check(lib().polar_synth_bicm_llr_dev(self._h, C.c_int(_constellation_id(constellation)), C.c_uint64(seed), C.c_uint64(trial0),
                                               C.c_long(B), C.c_double(snr_db), C.c_void_p(llr_ptr),
                                               C.c_void_p(info_ptr), _stream_ptr(stream)))
 
@@ -344,7 +344,7 @@ class PolarCode:
         Ls = np.ascontiguousarray(list_size_vec, np.uint8)
         enabled = np.ascontiguousarray(enabled, np.uint8)
         assert err.dtype == np.uint64 and run.dtype == np.uint64
-        _check(lib().polar_mc_batch_bicm(self._h, C.c_int(constellation), C.c_uint64(seed), C.c_uint64(t0), C.c_long(T),
+        _check(lib().polar_mc_batch_bicm(self._h, C.c_int(_constellation_id(constellation)), C.c_uint64(seed), C.c_uint64(t0), C.c_long(T),
                                          C.c_long(stride), _p(snr, _dp), C.c_int(len(snr)), _p(Ls, _u8p),
                                          C.c_int(len(Ls)), _p(enabled, _u8p), _p(err, _u64p), _p(run, _u64p)))
 

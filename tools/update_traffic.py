@@ -3,12 +3,17 @@
 prescribes — see tools/pmc_summary.py) for the bench.py default workload, so that bench.py can
 report roofline.traffic next to the live-measured kernel time.
 usage: tools/update_traffic.py profiles/r01/<name>_pmc.json n K crc L batch"""
+import hashlib
 import json
+import os
 import sys
 
 src, n, K, crc, L, batch = sys.argv[1], *map(int, sys.argv[2:7])
 d = json.load(open(src))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {"config": {"n": n, "K": K, "crc": crc, "L": L, "batch": batch},
+       # the library this profile was taken with: bench.py reports the counters only when it runs the same file
+       "lib_sha256": hashlib.sha256(open(os.path.join(ROOT, "polar_amd", "libpolar_amd.so"), "rb").read()).hexdigest(),
        "traffic_bytes_per_launch": d["hbm_traffic_per_launch"]["total_bytes"],
        "read_bytes_corrected": d["hbm_traffic_per_launch"]["read_bytes_corrected"],
        "write_bytes": d["hbm_traffic_per_launch"]["write_bytes"],
