@@ -6,6 +6,17 @@
 
 #include "polar_device.h"
 
+#ifndef POLAR_NO_COLD_HINTS
+#define POLAR_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#define POLAR_LIKELY(x) __builtin_expect(!!(x), 1)
+#else
+#define POLAR_UNLIKELY(x) (x)
+#define POLAR_LIKELY(x) (x)
+#endif
+// second batch of layout hints (measured: within the run-to-run noise on top of the first two; kept)
+#define POLAR_UNLIKELY2(x) POLAR_UNLIKELY(x)
+#define POLAR_LIKELY2(x) POLAR_LIKELY(x)
+
 namespace {
 
 // LDS tables of the fp64 exp / log routines: T[64] = 2^(f/64), RC[129] = 1/(1+j/128), LC[129] = log(1+j/128)
@@ -105,9 +116,28 @@ __device__ __forceinline__ double f_node_e(double a, double b, u64 &guard) {
     // both E-form: exact value, or (min-sum, :442-446) the smaller |x| = the larger E
     double r = __builtin_amdgcn_inverse_ballot_w64(m_hi) ? q : mx;
     // one L-form -> the E-form input (mn); both L-form -> the smaller |x| (mn)
-    if (m_l) r = __builtin_amdgcn_inverse_ballot_w64(m_l) ? mn : r;
+    // (POLAR_UNLIKELY: the block is laid out away from the hot path. The list kernel's code is several times the 64-KiB
+    // instruction cache two CUs share, and rarely-taken blocks sitting between the hot ones cost fetch misses on every
+    // pass: marking this branch and the one in g_node_e measured +5 % on the headline kernel.)
+    if (POLAR_UNLIKELY(m_l != 0)) r = __builtin_amdgcn_inverse_ballot_w64(m_l) ? mn : r;
     return ed_with_sign(r, __double2hiint(a) ^ __double2hiint(b));
 }
+// the same node with the guard kept PER LANE: `gacc` = the smallest distance seen so far between a node's smaller E and the
+// threshold; the codeword is flagged at its end when any of its lanes came within 2e-10 (relative) of it. One add and one
+// min instead of a second compare, two scalar mask operations and the merge into the wave mask — which the register
+// allocator keeps in a VGPR pair (two more VALU instructions per node).
+__device__ __forceinline__ double f_node_e_acc(double a, double b, double &gacc) {
+    const double fa = fabs(a), fb = fabs(b);
+    const double mx = __builtin_fmax(fa, fb), mn = __builtin_fmin(fa, fb);
+    const double q = ed_div(fa + fb, __builtin_fma(fa, fb, 1.0));
+    const u64 m_hi = __builtin_amdgcn_fcmp(mn, ED_C40_HI, 2);            // mn > e^-40 (1 + 1e-10): certainly |x| < 40
+    const u64 m_l = __builtin_amdgcn_fcmp(mx, 1.0, 2);                   // an L-form input (rare)
+    gacc = __builtin_fmin(gacc, fabs(mn - ED_C40_HI));
+    double r = __builtin_amdgcn_inverse_ballot_w64(m_hi) ? q : mx;
+    if (POLAR_UNLIKELY(m_l != 0)) r = __builtin_amdgcn_inverse_ballot_w64(m_l) ? mn : r;
+    return ed_with_sign(r, __double2hiint(a) ^ __double2hiint(b));
+}
+constexpr double ED_GACC_FLAG = 4.248354255291589e-18 * 2.0000001e-10;      // flagged: |mn - e^-40 (1 + 1e-10)| <= this
 // general natural logarithm of a positive normal double (tables of log_1p2)
 __device__ __forceinline__ double ed_log(double x, const Tabs &tb) {
     const int hi = __double2hiint(x);
@@ -148,7 +178,7 @@ __device__ __forceinline__ double g_node_e(double a, double b, unsigned usign, c
     sg = same ? hb : sg;
     double res = ed_with_sign(r, sg);
     const u64 m_rare = __builtin_amdgcn_fcmp(hi, 1.0, 2) | __builtin_amdgcn_ballot_w64(same && p < ED_EMIN);
-    if (m_rare) {
+    if (POLAR_UNLIKELY(m_rare != 0)) {
         const double sl = g_node_e_rare(a, b, ha, hb, tb.T);
         if (__builtin_amdgcn_inverse_ballot_w64(m_rare)) res = sl;
     }

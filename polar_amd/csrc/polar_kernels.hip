@@ -105,7 +105,7 @@ __device__ __forceinline__ double f_node(double a, double b, const Tabs &tb) {
         // |f| <= min(|a|,|b|): when that is within a few orders of the rounding noise (1e-16) the
         // reference's result IS its rounding noise (e.g. exactly 0 once e^a, e^b round to 1), so the
         // literal expression is evaluated for those (physically never occurring) elements.
-        if (mn < 9.5367431640625e-07) return f_literal(a, b);
+        if (POLAR_UNLIKELY2(mn < 9.5367431640625e-07)) return f_literal(a, b);
         return ms + h_diff(fabs(a + b), fabs(a - b), tb);
     }
 #endif
@@ -136,7 +136,7 @@ __device__ __forceinline__ void f_node2(double a0, double b0, double a1, double 
         const bool t0 = e0 && mn0 < 9.5367431640625e-07, t1 = e1 && mn1 < 9.5367431640625e-07;
         if (e0) r0 = x0;
         if (e1) r1 = x1;
-        if (wave_any(t0 || t1)) {                    // noise regime (see f_node)
+        if (POLAR_UNLIKELY2(wave_any(t0 || t1))) {                    // noise regime (see f_node)
             if (t0) r0 = f_literal(a0, b0);
             if (t1) r1 = f_literal(a1, b1);
         }
@@ -156,7 +156,7 @@ __device__ __forceinline__ double g_node(double a, double b, unsigned u) {
 __device__ __forceinline__ void softplus_pair(double a, bool skip, const Tabs &tb, double &sneg, double &spos) {
     double hx = 0.0;
     if (!skip) {
-        if (a < 9.5367431640625e-07) {            // noise regime: literal expressions (see f_node)
+        if (POLAR_UNLIKELY2(a < 9.5367431640625e-07)) {            // noise regime: literal expressions (see f_node)
             sneg = softplus_literal(-a);
             spos = softplus_literal(a);
             return;
@@ -185,13 +185,13 @@ __device__ __forceinline__ void leaf_terms(double leaf, bool active, const Tabs 
         const bool isl = m > 1.0;
         neg = (__double2hiint(leaf) < 0) && m != 1.0;
         al = m;
-        if (wave_any(active && !isl)) {
+        if (POLAR_LIKELY2(wave_any(active && !isl))) {
             const double l = -ed_log(__builtin_fmin(__builtin_fmax(m, ED_EMIN), 1.0), tb);
             if (!isl) al = l;
         }
         const double onep = 1.0 + m;                 // == 1 exactly from E <= 2^-53 on, as the reference's 1 + e^-|x|
         sneg = 0.0;
-        if (wave_any(active && !isl && onep != 1.0)) {
+        if (POLAR_LIKELY2(wave_any(active && !isl && onep != 1.0))) {
             const double h = log_1p2(__builtin_fmin(onep, 2.0), tb);
             if (!isl) sneg = h;
         }
@@ -219,6 +219,12 @@ __device__ __forceinline__ const double *ch_row(const PolarDecodeParams &p, size
 // LDS_LOG : log2 of the largest layer size kept in LDS
 #ifndef FU
 #define FU 4
+#endif
+#ifndef POLAR_SKIP_L1
+#define POLAR_SKIP_L1 1      // the layer of size 1 is never stored (+0.45 %)
+#endif
+#ifndef POLAR_NO_SADDR
+#define POLAR_SADDR 1        // HBM rows of the four-layer visits addressed as SGPR base + 32-bit lane offset (+0.4 %)
 #endif
 #ifndef OCC
 #define OCC 4
@@ -264,8 +270,15 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     if (WPB > 1) __syncthreads();
     const Tabs tb = {tabs, tabs + 64, tabs + 64 + 129};
     u64 guard = 0;                                  // (ED) wave mask of lanes with an undecidable |x| < 40 test
+#ifdef POLAR_GMIN
+    double gacc = __builtin_inf();                  // (ED) per lane: smallest distance of a node's smaller E to the |x| < 40 threshold
+#endif
     auto FN = [&](double a, double b) -> double {
+#ifdef POLAR_GMIN
+        if constexpr (ED) return f_node_e_acc(a, b, gacc); else return f_node(a, b, tb);
+#else
         if constexpr (ED) return f_node_e(a, b, guard); else return f_node(a, b, tb);
+#endif
     };
     // g-node of element with partial-sum bit `bi` of the word `cw_` (u = (cw_ >> bi) & 1)
     auto GN = [&](double a, double b, uint32_t cw_, int bi) -> double {
@@ -303,12 +316,19 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         const bool valid = (cwi < Bv);
         const long cw = (p.cw_list && valid) ? (long)p.cw_list[cwi] : cwi;   // codeword (row of llr / out)
         guard = 0;
+#ifdef POLAR_GMIN
+        gacc = __builtin_inf();
+#endif
         auto cw_of_lane = [&](int ln) -> size_t {
             const long i = g0 + ln / GS;
             return p.cw_list ? (size_t)p.cw_list[i < Bv ? i : Bv - 1] : (size_t)i;     // (lanes past the end of the work list: any valid row)
         };
         auto FN2 = [&](double a0_, double b0_, double a1_, double b1_, double &r0_, double &r1_) {
+#ifdef POLAR_GMIN
+            if constexpr (ED) { r0_ = f_node_e_acc(a0_, b0_, gacc); r1_ = f_node_e_acc(a1_, b1_, gacc); }
+#else
             if constexpr (ED) { r0_ = f_node_e(a0_, b0_, guard); r1_ = f_node_e(a1_, b1_, guard); }
+#endif
             else f_node2(a0_, b0_, a1_, b1_, tb, r0_, r1_);
         };
 
@@ -430,7 +450,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
             const int lam_top = (phi == phi_start && forced_top) ? forced_top : (phi ? (n - __builtin_ctz((unsigned)phi)) : 1);
             double leaf = 0.0;
             for (int lam = lam_top; lam <= lam_stop; ++lam) {
-                if (tbl && lam <= 2 && phi >= S2) {
+                if (POLAR_UNLIKELY2(tbl && lam <= 2 && phi >= S2)) {
                     // phi = N/4, N/2, 3N/4: the visits of layers 1 and 2 are replaced by the table build
                     const int kind = phi / S2;                      // 1: h (g of the shared layer 1), 2: f, 3: g
                     LANE_CTX
@@ -507,7 +527,12 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
 #ifdef POLAR_NO_FUSED4
                     const bool deep = false;
 #else
+#ifdef POLAR_SADDR
+                    // (not from the prefix buffer, whose rows are per codeword: once per codeword, left to the two-layer body)
+                    const bool deep = (lam + 3 <= lam_stop) && (phi & (S - 1)) == 0 && !(lam > 1 && p.prefix_q > 0 && 2 * S >= p.prefix_q && phi < 2 * S);
+#else
                     const bool deep = (lam + 3 <= lam_stop) && (phi & (S - 1)) == 0;        // four layers at once (else two)
+#endif
 #endif
                     if (active) {
                         LANE_CTX
@@ -579,8 +604,19 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                         // from the channel values at its only later reader, the g-visit of layer 2 at phi = 3N/4: -9 % HBM
                         // bytes, but -1.7 % throughput; the re-derivation pass itself is slower than the traffic it saves)
                         const bool tsrc = tbl && lam == 3 && phi >= S2;       // inputs come from the layer-2 table
-                        auto fused4 = [&](const double *inp, double *o0, double *o1, double *o2, double *o3, auto NTT, auto TSS) {
+                        // GMM: bit k set = o_k is HBM-resident and passed as the UNIFORM base of its rows (the lane offset is added as a
+                        // 32-bit register offset: global_load/store with an SGPR base, no 64-bit VALU add per access)
+                        auto fused4 = [&](const double *inp, double *o0, double *o1, double *o2, double *o3, auto NTT, auto TSS, auto GMM) {
                             constexpr bool TS = decltype(TSS)::value;
+                            constexpr int GM = decltype(GMM)::value;
+                            const uint32_t lb = (uint32_t)lane * 8u;
+                            const uint32_t lin = (uint32_t)(gbase + pin) * 8u;
+                            const char *inu = reinterpret_cast<const char *>(g_llr + (size_t)(2 * S - 2 * SL) * 64);      // source rows (uniform)
+                            auto st = [&](double *o, auto gbit, auto ntbit, size_t row, double val) {
+                                constexpr bool G_ = decltype(gbit)::value, N_ = decltype(ntbit)::value;
+                                double *q_ = G_ ? reinterpret_cast<double *>(reinterpret_cast<char *>(o) + row * 512 + lb) : o + row * 64;
+                                if (N_) __builtin_nontemporal_store(val, q_); else *q_ = val;
+                            };
                             // streaming (non-temporal) accesses for the layers of size >= 64 (bit 0: input, 1: o0, 2: o1): they
                             // are written once and read once or twice much later; the layers of size 16 and 32 stay cacheable
                             // (measured +1.7 %)
@@ -614,8 +650,16 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
 #endif
 #pragma unroll
                                     for (int m = 0; m < 8; ++m) {
+#ifdef POLAR_SADDR
+                                        // (never the prefix buffer here: `deep` excludes it)
+                                        const double *pa = reinterpret_cast<const double *>(inu + (size_t)(jj + m * E) * 512 + lin);
+                                        const double *pb = reinterpret_cast<const double *>(inu + (size_t)(jj + m * E + S) * 512 + lin);
+                                        if (NT & 1) { a[m] = __builtin_nontemporal_load(pa); b[m] = __builtin_nontemporal_load(pb); }
+                                        else { a[m] = *pa; b[m] = *pb; }
+#else
                                         if (NT & 1) { a[m] = __builtin_nontemporal_load(inp + (size_t)(jj + m * E) * istr); b[m] = __builtin_nontemporal_load(inp + (size_t)(jj + m * E + S) * istr); }
                                         else { a[m] = inp[(size_t)(jj + m * E) * istr]; b[m] = inp[(size_t)(jj + m * E + S) * istr]; }
+#endif
                                     }
                                 }
                             };
@@ -651,14 +695,18 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
 #else
                                 const int js = j;
 #endif
+                                typedef std::integral_constant<bool, (GM & 1) != 0> G0; typedef std::integral_constant<bool, (GM & 2) != 0> G1;
+                                typedef std::integral_constant<bool, (GM & 4) != 0> G2; typedef std::integral_constant<bool, (GM & 8) != 0> G3;
+                                typedef std::integral_constant<bool, (NT & 2) != 0> N0; typedef std::integral_constant<bool, (NT & 4) != 0> N1;
+                                typedef std::integral_constant<bool, (NT & 8) != 0> N2; typedef std::integral_constant<bool, false> N3;
 #pragma unroll
-                                for (int m = 0; m < 8; ++m) { if (NT & 2) __builtin_nontemporal_store(v[m], o0 + (size_t)(js + m * E) * 64); else o0[(size_t)(js + m * E) * 64] = v[m]; }
+                                for (int m = 0; m < 8; ++m) st(o0, G0{}, N0{}, (size_t)(js + m * E), v[m]);
 #pragma unroll
-                                for (int m = 0; m < 4; ++m) { v[m] = FN(v[m], v[m + 4]); if (NT & 4) __builtin_nontemporal_store(v[m], o1 + (size_t)(js + m * E) * 64); else o1[(size_t)(js + m * E) * 64] = v[m]; }
+                                for (int m = 0; m < 4; ++m) { v[m] = FN(v[m], v[m + 4]); st(o1, G1{}, N1{}, (size_t)(js + m * E), v[m]); }
 #pragma unroll
-                                for (int m = 0; m < 2; ++m) { v[m] = FN(v[m], v[m + 2]); if (NT & 8) __builtin_nontemporal_store(v[m], o2 + (size_t)(js + m * E) * 64); else o2[(size_t)(js + m * E) * 64] = v[m]; }
+                                for (int m = 0; m < 2; ++m) { v[m] = FN(v[m], v[m + 2]); st(o2, G2{}, N2{}, (size_t)(js + m * E), v[m]); }
                                 v[0] = FN(v[0], v[1]);
-                                o3[(size_t)j * 64] = v[0];
+                                st(o3, G3{}, N3{}, (size_t)j, v[0]);
                                 leaf = v[0];            // (the leaf value when S/8 == 1)
                             }
                         };
@@ -673,12 +721,21 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
 #define POLAR_NTM(x) std::integral_constant<int, 0>{}
 #endif
                             typedef std::integral_constant<bool, false> TS0;
-                            if (tsrc) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_GROW(Q), POLAR_GROW(E8), POLAR_NTM(6), std::integral_constant<bool, true>{});
-                            else if (E8 > SL) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_GROW(Q), POLAR_GROW(E8), POLAR_NTM(7), TS0{});      // S >= 128
-                            else if (Q > SL) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_GROW(Q), POLAR_LROW(E8), POLAR_NTM(3), TS0{});   // S = 64
-                            else if (H > SL) fused4(gin, POLAR_GROW(S), POLAR_GROW(H), POLAR_LROW(Q), POLAR_LROW(E8), POLAR_NTM(1), TS0{});   // S = 32: input 64
-                            else if (S > SL) fused4(gin, POLAR_GROW(S), POLAR_LROW(H), POLAR_LROW(Q), POLAR_LROW(E8), POLAR_NTM(0), TS0{});                 // S = 16: input 32
-                            else fused4(gin, POLAR_LROW(S), POLAR_LROW(H), POLAR_LROW(Q), POLAR_LROW(E8), std::integral_constant<int, 0>{}, TS0{});        // S = 8: input 16
+#ifdef POLAR_SADDR
+#define POLAR_GOUT(T) (g_llr + (size_t)((T) - 2 * SL) * 64)
+#define POLAR_GMK(x) std::integral_constant<int, (x)>{}
+#else
+#define POLAR_GOUT(T) POLAR_GROW(T)
+#define POLAR_GMK(x) std::integral_constant<int, 0>{}
+#endif
+                            if (tsrc) fused4(gin, POLAR_GOUT(S), POLAR_GOUT(H), POLAR_GOUT(Q), POLAR_GOUT(E8), POLAR_NTM(6), std::integral_constant<bool, true>{}, POLAR_GMK(15));
+                            else if (E8 > SL) fused4(gin, POLAR_GOUT(S), POLAR_GOUT(H), POLAR_GOUT(Q), POLAR_GOUT(E8), POLAR_NTM(7), TS0{}, POLAR_GMK(15));      // S >= 128
+                            else if (Q > SL) fused4(gin, POLAR_GOUT(S), POLAR_GOUT(H), POLAR_GOUT(Q), POLAR_LROW(E8), POLAR_NTM(3), TS0{}, POLAR_GMK(7));   // S = 64
+                            else if (H > SL) fused4(gin, POLAR_GOUT(S), POLAR_GOUT(H), POLAR_LROW(Q), POLAR_LROW(E8), POLAR_NTM(1), TS0{}, POLAR_GMK(3));   // S = 32: input 64
+                            else if (S > SL) fused4(gin, POLAR_GOUT(S), POLAR_LROW(H), POLAR_LROW(Q), POLAR_LROW(E8), POLAR_NTM(0), TS0{}, POLAR_GMK(1));                 // S = 16: input 32
+                            else fused4(gin, POLAR_LROW(S), POLAR_LROW(H), POLAR_LROW(Q), POLAR_LROW(E8), std::integral_constant<int, 0>{}, TS0{}, POLAR_GMK(0));        // S = 8: input 16
+#undef POLAR_GOUT
+#undef POLAR_GMK
 #undef POLAR_NTM
                             pL.set(sh - 2, lig);
                             pL.set(sh - 3, lig);
@@ -715,14 +772,17 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                             for (int j = 0; j < S_; ++j) { a[j] = li[(size_t)j * 64]; b[j] = li[(size_t)(j + S_) * 64]; }
 #pragma unroll
                             for (int j = 0; j < S_; ++j) r[j] = odd ? GN(a[j], b[j], cb, j) : FN(a[j], b[j]);
+                            // (the layer of size 1 — the leaf value — is consumed from the register: nobody reads it back)
+                            if (S_ > 1 || !POLAR_SKIP_L1) {
 #pragma unroll
-                            for (int j = 0; j < S_; ++j) lo[(size_t)j * 64] = r[j];
+                                for (int j = 0; j < S_; ++j) lo[(size_t)j * 64] = r[j];
+                            }
                             // layer of size T = S_ >> d from the one above (registers), stored for its later g-visit
                             auto down = [&](auto TT) {
                                 constexpr int T = decltype(TT)::value;
                                 double *lt = lds_llr + (size_t)(T - 1) * 64 + lane;
 #pragma unroll
-                                for (int j = 0; j < T; ++j) { r[j] = FN(r[j], r[j + T]); lt[(size_t)j * 64] = r[j]; }
+                                for (int j = 0; j < T; ++j) { r[j] = FN(r[j], r[j + T]); if (T > 1 || !POLAR_SKIP_L1) lt[(size_t)j * 64] = r[j]; }
                             };
                             if constexpr (S_ >= 2) { if (below >= 1) down(std::integral_constant<int, S_ / 2>{}); }
                             if constexpr (S_ >= 4) { if (below >= 2) down(std::integral_constant<int, S_ / 4>{}); }
@@ -735,7 +795,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                         else if (S == 4) small(std::integral_constant<int, 4>{});
                         else if (S == 8) small(std::integral_constant<int, 8>{});
                         else small(std::integral_constant<int, 16>{});      // (lds_log = 5)
-                        for (int d = 0; d <= below; ++d) pL.set(sh - d, lig);
+                        for (int d = 0; d <= below; ++d) if (sh - d > 0 || !POLAR_SKIP_L1) pL.set(sh - d, lig);
                     }
                     wave_mem_fence();
                     PROF(S >= 4 ? 3 : 4)
@@ -957,7 +1017,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     // unfrozen) that comes out below 1e-8: the reference decides on the rounding noise of its own arithmetic
                     // there, which the LLR-domain kernel follows much further down than this one -> fallback pass
 #ifndef POLAR_NO_WEAK_GUARD
-                    if (ctl & 0x100u) guard |= __ballot(active && fabs(leaf) > 0.99999999 && fabs(leaf) <= 1.0);
+                    if (POLAR_UNLIKELY2(ctl & 0x100u)) guard |= __ballot(active && fabs(leaf) > 0.99999999 && fabs(leaf) <= 1.0);
 #endif
                 }
                 if (active) {
@@ -1009,7 +1069,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 bool c0 = active, c1 = active;
                 const bool need = (2 * nact > L);          // otherwise every fork continues
                 const bool full = (nact == L);
-                if (!wave_any(need && !full)) {
+                if (POLAR_LIKELY2(!wave_any(need && !full))) {
                     // List full (the usual case). Rank = number of better forks in the reference's order
                     // (metric desc = PM asc, fork index asc on ties, PolarCode.cpp:528-553). A bad fork
                     // whose lower bound is worse than every good fork (bl > gmax) can neither survive nor
@@ -1187,7 +1247,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 const u64 km = (__ballot(kill) >> gbase) & gmask;
                 const u64 bm = (__ballot(both) >> gbase) & gmask;
                 srcof[lane] = (unsigned char)lig;
-                if (wave_all(!active || full)) {
+                if (POLAR_LIKELY2(wave_all(!active || full))) {
                     // list full before the step => #kills == #clones: the kills are pushed (ascending l) and
                     // popped right back (LIFO) by the clones in ascending l, i.e. the r-th cloner revives the
                     // r-th LARGEST killed index; stack pointer and the entries below are untouched. One LDS
@@ -1241,7 +1301,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 // holds this path's previous word: a linked list per path, walked once at the end, so that
                 // neither clones nor flushes ever copy history (the reference copies it on every clone,
                 // PolarCode.cpp:574)
-                if ((t & 31) == 31) {
+                if (POLAR_UNLIKELY2((t & 31) == 31)) {
                     const int w = (int)(t >> 5);
                     if (active) {
                         g_hist[(size_t)w * 64 + lane] = hword;
@@ -1338,6 +1398,9 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         }
         if constexpr (ED) {
             // codewords with an undecidable |x| < 40 test go to the LLR-domain kernel (host: fallback pass)
+#ifdef POLAR_GMIN
+            guard |= __ballot(gacc <= ED_GACC_FLAG);
+#endif
             if (valid && lig == 0 && ((guard >> gbase) & gmask) != 0) p.flags[cw] = 1;
         }
         wave_mem_fence();

@@ -28,6 +28,9 @@
 
 #include "polar_kernels.h"
 #include "polar_device.h"
+// (the block-placement hints of polar_edom.h pay where the code is several times the instruction cache — the list kernels,
+// +5 % — and cost 2 % here, where it fits)
+#define POLAR_NO_COLD_HINTS
 #include "polar_edom.h"
 
 namespace {

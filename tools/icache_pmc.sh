@@ -12,7 +12,7 @@ import csv, glob, collections
 for f in sorted(glob.glob("$R/gpurun_out/ic*/pmc_counter_collection.csv")):
     acc = collections.defaultdict(float); n = collections.Counter()
     for r in csv.DictReader(open(f)):
-        if "0, true>" in r["Kernel_Name"]:
+        if "0, true" in r["Kernel_Name"] and "<32" in r["Kernel_Name"]:
             acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
     print({c: f"{v / n[c]:.4g}" for c, v in acc.items()})
 PY
