@@ -94,6 +94,11 @@ int polar_decode_scl_llr_batch_dev(polar_code_t *h, const double *d_llr, long B,
 int polar_decode_scl_llr_batch_f32(polar_code_t *h, const float *llr, long B, int L, uint8_t *out);
 int polar_decode_scl_llr_batch_dev_f32(polar_code_t *h, const float *d_llr, long B, int L, uint8_t *d_out,
                                        double *d_pm, void *stream);
+/* Pre-size the handle's device scratch for decodes of up to B codewords at list size L (runs one decode on generated
+ * inputs and waits for it). The device-resident entry points grow their scratch on demand — a hipFree/hipMalloc, i.e. an
+ * implicit device synchronisation, whenever B or L exceeds anything seen before; after polar_reserve they do not allocate
+ * for calls within (B, L). */
+int polar_reserve(polar_code_t *h, long B, int L);
 /* same, recording two hipEvent_t (may be NULL) on `stream` immediately around the launch of the
  * dominant kernel (scl_decode_llr_kernel), i.e. after the small all-frozen-prefix kernel — for
  * bench.py's roofline line */
@@ -195,7 +200,14 @@ int polar_set_tuning(polar_code_t *h, int waves_per_cu, int lds_log);
 /* node arithmetic of decode_scl_llr: 0 = automatic (exp-domain kernel for list sizes >= 5, LLR-domain kernel
  * below), 1 = LLR-domain kernel only (table-driven exp/log1p f-node, the round-1 path), 2 = exp-domain kernel
  * (f-node = one division; codewords it cannot decide safely are flagged on the device and decoded again by the
- * LLR-domain kernel in the same call). Decoded bits are the reference's in every mode. */
+ * LLR-domain kernel in the same call).
+ * Decoded bits are the reference's in every mode for codes a construction produces for its channel (every BASELINE
+ * configuration, the golden vectors, the fuzz slice of the -m gpu suite). Where unfrozen leaves lie in the worst synthetic
+ * channels (explicit tables, rates near 1) the reference itself decides on the rounding noise of glibc's exp/log, which no
+ * other arithmetic reproduces bit for bit: the handle marks such leaves at creation (BEC(1/2) capacity below 1e-3) and every
+ * codeword in which one of them comes out below 1e-8 is decoded by the LLR-domain kernel whatever the mode, so automatic
+ * mode is never worse there than mode 1 (DESIGN.md "Where bit-exactness ends"; tests/test_gpu_fuzz.py). With list sizes
+ * below 3 mode 2 falls back to the LLR-domain kernel (the exp-domain kernels exist for groups of 4 lanes and more). */
 int polar_set_mode(polar_code_t *h, int mode);
 
 #ifdef __cplusplus

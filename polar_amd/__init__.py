@@ -235,6 +235,10 @@ class PolarCode:
         if self.crc_size:
             _check(lib().polar_set_crc_matrix(self._h, _p(m, _u8p)))
 
+    def reserve(self, B, list_size):
+        """Pre-size the device scratch for decodes of up to B codewords at this list size (polar_reserve)."""
+        _check(lib().polar_reserve(self._h, C.c_long(B), C.c_int(list_size)))
+
     def set_tuning(self, waves_per_cu=0, lds_log=0):
         _check(lib().polar_set_tuning(self._h, C.c_int(waves_per_cu), C.c_int(lds_log)))
 

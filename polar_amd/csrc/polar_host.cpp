@@ -777,6 +777,26 @@ int polar_synth_llr_dev(polar_code_t *h, uint64_t seed, uint64_t trial0, long B,
     return POLAR_OK;
 }
 
+// Pre-size every device scratch buffer a decode of (B codewords, list size L) needs, by running one on generated inputs:
+// afterwards polar_decode_scl_llr_batch_dev* calls of at most that size allocate nothing (no hipFree / hipMalloc, i.e. no
+// implicit device synchronisation, inside the nominally asynchronous calls).
+int polar_reserve(polar_code_t *h, long B, int L) {
+    if (!h) return fail(POLAR_E_ARG, "NULL handle");
+    if (B <= 0) return B == 0 ? POLAR_OK : fail(POLAR_E_ARG, "negative batch");
+    DevGuard dg_;
+    int rc = ensure_device(h, dg_);
+    if (rc) return rc;
+    DevBuf<double> llr;
+    DevBuf<uint8_t> out;
+    if ((rc = llr.ensure((size_t)B * h->N)) || (rc = out.ensure((size_t)B * h->K))) { llr.release(); out.release(); return rc; }
+    rc = polar_synth_llr_dev(h, 1, 0, B, polar_snr_sqrt_linear(h, 2.0), llr.p, nullptr, nullptr);
+    if (!rc) rc = polar_decode_scl_llr_batch_dev(h, llr.p, B, L, out.p, nullptr, nullptr);
+    hipError_t e = hipDeviceSynchronize();
+    llr.release(); out.release();
+    if (!rc && e != hipSuccess) return fail(POLAR_E_DEVICE, "polar_reserve: %s", hipGetErrorString(e));
+    return rc;
+}
+
 int polar_count_errors_dev(polar_code_t *h, const uint8_t *d_a, const uint8_t *d_b, long B,
                            unsigned long long *d_err_count, void *stream) {
     if (!h || !d_a || !d_b || !d_err_count) return fail(POLAR_E_ARG, "NULL argument");

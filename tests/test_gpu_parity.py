@@ -357,3 +357,25 @@ def test_degenerate_rows_mixed_with_normal_ones(built_lib, oracle_built, L):
     got = g.decode_scl_llr(llr, L)
     bad = [int(r) for r in range(384) if (got[r] != o.decode_scl_llr(llr[r], L)).any()]
     assert not bad, f"rows {bad} differ (special rows: {sorted(int(r) for r in rows)})"
+
+
+@pytest.mark.parametrize("L", [1, 4, 32])
+def test_one_codeword_at_a_time_equals_the_batch(built_lib, oracle_built, L):
+    """The reference's loops call the decoder one codeword at a time (PolarCode.cpp:756, PolarM/main_MC_CC_Comparison.m:96):
+    B = 1 through the host-pointer ABI returns, codeword for codeword, what one batched call returns (and the oracle's bits).
+    Latency / crossover table: profiles/r03/latency_table.json, DESIGN.md §5c."""
+    o, g = _pair(11, 1024, 16)
+    llr, _ = o.synth_llr(31, 0, 24, o.snr_sqrt_linear(1.5))
+    batch = g.decode_scl_llr(llr, L)
+    assert (batch == o.decode_scl_llr(llr, L)).all()
+    for i in range(24):
+        assert (g.decode_scl_llr(llr[i], L) == batch[i]).all(), i
+
+
+def test_reserve_presizes_the_scratch(built_lib, oracle_built):
+    """polar_reserve(B, L): decodes of at most that size afterwards find every scratch buffer in place (same results)."""
+    o, g = _pair(9, 256, 8)
+    g.reserve(3000, 32)
+    llr, _ = o.synth_llr(9, 0, 700, o.snr_sqrt_linear(2.0))
+    for L in (1, 4, 32):
+        assert (g.decode_scl_llr(llr, L) == o.decode_scl_llr(llr, L)).all(), L
