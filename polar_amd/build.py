@@ -45,6 +45,20 @@ def _newer(target, deps):
     return any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in deps)
 
 
+def _fingerprint(cmd, files):
+    """sha256 of the compile command and of the CONTENT of the source and every header it includes: an object is rebuilt when
+    this changes, not when a timestamp does (a checkout or a copy touches files without changing them, and a rebuilt library is
+    not byte-identical — the committed rocprofv3 profiles are keyed by the library's hash, bench.py)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(cmd).encode())
+    for f in sorted(set(files)):
+        try:
+            h.update(f.encode()); h.update(open(f, "rb").read())
+        except OSError:
+            h.update(b"<missing>")
+    return h.hexdigest()
+
+
 def _deps(obj, fallback):
     """Headers an object really includes (the compiler's -MD file next to it); every header when there is none yet."""
     d = obj + ".d"
@@ -57,7 +71,7 @@ def _deps(obj, fallback):
     return [x for x in parts[1].split() if x.startswith(ROOT)]
 
 
-def build(force=False, verbose=False, profile=False):
+def build(force=False, verbose=False, profile=False, bless=False):
     """profile=True builds the instrumented variant libpolar_amd_prof.so (-DPOLAR_PROFILE: per-phase
     cycle counters, tools/phase_profile.py); never used by the product path."""
     global LIB
@@ -75,22 +89,34 @@ def build(force=False, verbose=False, profile=False):
         src = os.path.join(CSRC, s)
         obj = os.path.join(BUILD, s + otag + tag + ".o")
         objs.append(obj)
-        if force or _newer(obj, [src] + _deps(obj, headers)):
-            cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-                   "-Wall", "-Wno-unused-function", "-x", "hip", "-I", INC, "-I", CSRC, "-MD", "-MF", obj + ".d",
-                   "-c", src, "-o", obj]
-            if profile:
-                cmd.insert(1, "-DPOLAR_PROFILE")
-            for d in defs + os.environ.get("POLAR_DEFS", "").split():
-                cmd.insert(1, "-D" + d)
-            cmd[1:1] = os.environ.get("POLAR_HIPCC_FLAGS", "").split()    # A/B experiments with compiler options
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+               "-Wall", "-Wno-unused-function", "-x", "hip", "-I", INC, "-I", CSRC, "-MD", "-MF", obj + ".d",
+               "-c", src, "-o", obj]
+        if profile:
+            cmd.insert(1, "-DPOLAR_PROFILE")
+        for d in defs + os.environ.get("POLAR_DEFS", "").split():
+            cmd.insert(1, "-D" + d)
+        cmd[1:1] = os.environ.get("POLAR_HIPCC_FLAGS", "").split()    # A/B experiments with compiler options
+        fp = _fingerprint(cmd, [src] + _deps(obj, headers))
+        stamp = obj + ".sha"
+        have = open(stamp).read().strip() if os.path.exists(stamp) and os.path.exists(obj) else None
+        if bless and os.path.exists(obj):
+            # adopt the existing object as built from the current sources (objects that predate the stamps)
+            open(stamp, "w").write(fp)
+            continue
+        if force or have != fp:
             if verbose:
                 print(" ".join(cmd))
-            jobs.append(cmd)
+            jobs.append((cmd, stamp, obj, src, headers))
     if jobs:   # the translation units are independent: compile them side by side
         from concurrent.futures import ThreadPoolExecutor
+
+        def run(job):
+            cmd, stamp, obj, src, hdrs = job
+            subprocess.check_call(cmd)
+            open(stamp, "w").write(_fingerprint(cmd, [src] + _deps(obj, hdrs)))     # (with the dependency list the compiler just wrote)
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
-            list(ex.map(subprocess.check_call, jobs))
+            list(ex.map(run, jobs))
     if force or _newer(lib_out, objs):
         tl = _torch_lib()
         cmd = [_hipcc(), "-shared", "-fPIC", "-o", lib_out] + objs
@@ -121,4 +147,4 @@ def build_cli(force=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, profile="--profile" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True, profile="--profile" in sys.argv, bless="--bless" in sys.argv))
