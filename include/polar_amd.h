@@ -197,7 +197,7 @@ int polar_mc_construction(int n, int constellation, double design_snr_db, uint64
 
 /* tuning knobs (0 = default): waves resident per CU and LDS-resident layer exponent */
 int polar_set_tuning(polar_code_t *h, int waves_per_cu, int lds_log);
-/* node arithmetic of decode_scl_llr: 0 = automatic (exp-domain kernel for list sizes >= 5, LLR-domain kernel
+/* node arithmetic of decode_scl_llr: 0 = automatic (exp-domain kernel for list sizes >= 3, LLR-domain kernel
  * below), 1 = LLR-domain kernel only (table-driven exp/log1p f-node, the round-1 path), 2 = exp-domain kernel
  * (f-node = one division; codewords it cannot decide safely are flagged on the device and decoded again by the
  * LLR-domain kernel in the same call).
@@ -209,6 +209,8 @@ int polar_set_tuning(polar_code_t *h, int waves_per_cu, int lds_log);
  * mode is never worse there than mode 1 (DESIGN.md "Where bit-exactness ends"; tests/test_gpu_fuzz.py). With list sizes
  * below 3 mode 2 falls back to the LLR-domain kernel (the exp-domain kernels exist for groups of 4 lanes and more). */
 int polar_set_mode(polar_code_t *h, int mode);
+/* test hook: how many unfrozen leaves the handle classified as weak at creation (BEC(1/2) capacity below 1e-3; see above) */
+int polar_debug_weak_leaves(const polar_code_t *h);
 
 #ifdef __cplusplus
 }

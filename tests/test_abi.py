@@ -125,3 +125,22 @@ def test_mex_gateway_compiles_syntax_only():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(root, "tests", "mex_stub"),
                            "-I", os.path.join(root, "include"), os.path.join(root, "polar_amd", "matlab", "polar_mex.cpp")])
+
+
+def test_weak_unfrozen_leaves_are_classified_at_creation(built_lib):
+    """Host side of the round-3 parity guard (DESIGN.md "Where bit-exactness ends"): codes a construction produces for an
+    ordinary channel have no unfrozen leaf in the worst synthetic channels; rates near 1 / a design parameter that does not
+    describe the channel do; the reference's 16-ASK BICM table has one (its bit levels are unequal: under a BEC it looks
+    weak, on its own channel it is not — the device guard looks at the VALUE before it acts)."""
+    import polar_amd
+    L = polar_amd.lib()
+    L.polar_debug_weak_leaves.restype = C.c_int
+    L.polar_debug_weak_leaves.argtypes = [C.c_void_p]
+    def weak(g):
+        return L.polar_debug_weak_leaves(g._h)
+    for (n, K, eps, crc) in [(11, 1024, 0.32, 16), (11, 1024, 0.32, 0), (9, 256, 0.32, 0), (10, 512, 0.32, 0), (10, 614, 0.5, 0), (4, 10, 0.32, 0)]:
+        assert weak(polar_amd.PolarCode(n, K, eps, crc)) == 0, (n, K, eps, crc)
+    assert weak(polar_amd.PolarCode(9, 505, 0.7, 0)) > 100
+    assert weak(polar_amd.PolarCode(10, 1022, 0.32, 0)) > 300
+    counts = G.load()[0]["cfg5_n10_k512_ask16/counts"]
+    assert weak(polar_amd.PolarCode.from_counts(counts, 512)) == 1

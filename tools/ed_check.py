@@ -18,6 +18,8 @@ libc = C.CDLL(None)
 CODES = [(11, 1024, 16, 32), (11, 1024, 16, 8), (10, 512, 0, 8), (9, 256, 8, 32), (11, 1024, 0, 16), (11, 1536, 11, 64)]
 if os.environ.get("ED_ONLY32"):
     CODES = CODES[:1]
+if os.environ.get("ED_SMALL"):       # the 4-lane groups (lists of 3 and 4: exp-domain kernel in automatic mode since round 3)
+    CODES = [(11, 1024, 16, 4), (11, 1024, 0, 3), (10, 512, 0, 4), (9, 256, 8, 3), (12, 2048, 16, 4), (8, 100, 4, 4), (11, 1400, 0, 4)]
 bad_total = 0
 for (n, K, crc, L) in CODES:
     libc.srand(1)
