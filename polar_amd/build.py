@@ -48,12 +48,18 @@ def _newer(target, deps):
 def _fingerprint(cmd, files):
     """sha256 of the compile command and of the CONTENT of the source and every header it includes: an object is rebuilt when
     this changes, not when a timestamp does (a checkout or a copy touches files without changing them, and a rebuilt library is
-    not byte-identical — the committed rocprofv3 profiles are keyed by the library's hash, bench.py)."""
+    not byte-identical — the committed rocprofv3 profiles are keyed by the library's hash, bench.py). Paths enter relative to
+    the repository root: the tree is copied to another place on the GPU box and must not rebuild there."""
     import hashlib
-    h = hashlib.sha256(" ".join(cmd).encode())
-    for f in sorted(set(files)):
+    root = os.path.realpath(ROOT)
+
+    def rel(x):
+        rx = os.path.realpath(x) if os.path.isabs(x) else x
+        return "<root>" + rx[len(root):] if os.path.isabs(rx) and rx.startswith(root) else x
+    h = hashlib.sha256(" ".join(rel(c) for c in cmd[1:]).encode())     # (not the compiler's own path)
+    for f in sorted(set(files), key=rel):
         try:
-            h.update(f.encode()); h.update(open(f, "rb").read())
+            h.update(rel(f).encode()); h.update(open(f, "rb").read())
         except OSError:
             h.update(b"<missing>")
     return h.hexdigest()
@@ -68,7 +74,18 @@ def _deps(obj, fallback):
     parts = txt.split(":", 1)
     if len(parts) < 2:
         return fallback
-    return [x for x in parts[1].split() if x.startswith(ROOT)]
+    # (the .d file holds the absolute paths of the place the object was compiled in; the tree may have been copied since:
+    # re-anchor every in-tree header at THIS root by its path below polar_amd/ or include/)
+    out = []
+    for x in parts[1].split():
+        for anchor in ("/polar_amd/csrc/", "/include/"):
+            k = x.rfind(anchor)
+            if k >= 0 and not x.startswith("/opt/") and not x.startswith("/usr/"):
+                cand = os.path.join(ROOT, x[k + 1:])
+                if os.path.exists(cand):
+                    out.append(cand)
+                break
+    return out
 
 
 def build(force=False, verbose=False, profile=False, bless=False):
@@ -117,7 +134,15 @@ def build(force=False, verbose=False, profile=False, bless=False):
             open(stamp, "w").write(_fingerprint(cmd, [src] + _deps(obj, hdrs)))     # (with the dependency list the compiler just wrote)
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
             list(ex.map(run, jobs))
-    if force or _newer(lib_out, objs):
+    # (the link, too, is decided by content: the stamps of the objects it was made from)
+    import hashlib
+    link_fp = hashlib.sha256("".join(open(o + ".sha").read() if os.path.exists(o + ".sha") else "?" for o in objs).encode()).hexdigest()
+    link_stamp = os.path.join(BUILD, os.path.basename(lib_out) + ".sha")
+    have_link = open(link_stamp).read().strip() if os.path.exists(link_stamp) and os.path.exists(lib_out) else None
+    if bless and os.path.exists(lib_out):
+        open(link_stamp, "w").write(link_fp)
+        have_link = link_fp
+    if force or jobs or have_link != link_fp:
         tl = _torch_lib()
         cmd = [_hipcc(), "-shared", "-fPIC", "-o", lib_out] + objs
         if tl:
@@ -129,6 +154,7 @@ def build(force=False, verbose=False, profile=False, bless=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        open(link_stamp, "w").write(link_fp)
     return lib_out
 
 
