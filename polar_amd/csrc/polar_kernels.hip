@@ -220,14 +220,6 @@ __device__ __forceinline__ const double *ch_row(const PolarDecodeParams &p, size
 #ifndef FU
 #define FU 4
 #endif
-// the exact fast path of the unfrozen leaf (73 % of the steps at 2 dB) as the fall-through, the ranking path out of line
-#ifdef POLAR_FASTHINT
-#define POLAR_FASTHINT_L(x) POLAR_LIKELY(x)
-#define POLAR_FASTHINT_U(x) POLAR_UNLIKELY(x)
-#else
-#define POLAR_FASTHINT_L(x) (x)
-#define POLAR_FASTHINT_U(x) (x)
-#endif
 #ifndef POLAR_SKIP_L1
 #define POLAR_SKIP_L1 1      // the layer of size 1 is never stored (+0.45 %)
 #endif
@@ -651,11 +643,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                                         a[m] = CH(in0, i0); b[m] = CH(in0, i0 + 1);
                                     }
                                 } else {
-#ifdef POLAR_EXPERIMENT_FAKE_LD      // (measurement-only build: every pass re-reads the same 16 rows — cache hits instead of HBM reads)
-                                    const int jj = 0;
-#else
                                     const int jj = j;
-#endif
 #pragma unroll
                                     for (int m = 0; m < 8; ++m) {
 #ifdef POLAR_SADDR
@@ -671,22 +659,11 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                                     }
                                 }
                             };
-#ifdef POLAR_PF
-                            // L2 prefetch of the NEXT pass's 16 source rows with ONE scattered load: a row is four 128-B lines, so
-                            // the 64 lanes of a single global_load_dword touch every line of those rows (lane -> row (lane >> 2),
-                            // line (lane & 3)). It costs one VGPR and no wait: the value is dropped after the next pass's real loads
-                            // have been issued, and those then hit the L2 instead of paying the HBM latency per pass.
-                            const bool pf_on = !TS && !in_is_ch && !in_pre && E > 1;
-                            const uint32_t *pfp = pf_on ? reinterpret_cast<const uint32_t *>(g_llr + (size_t)(2 * S - 2 * SL) * 64) +
-                                                          ((size_t)(((lane >> 2) & 7) * E + (lane >> 5) * S) * 128 + (size_t)(lane & 3) * 32) : nullptr;
-                            uint32_t pfv = 0;
-#endif
+                            // (measured and dropped, round 3: an L2 prefetch of the NEXT pass's 16 source rows by ONE scattered
+                            // global_load_dword touching their 64 lines — no VGPRs, no wait: -1.5 %; the kernel is on the bandwidth
+                            // ceiling of its access pattern, asking earlier gains nothing)
                             for (int j = 0; j < E; ++j) {
                                 load8(j);
-#ifdef POLAR_PF
-                                asm volatile("" : "+v"(pfv));
-                                if (pf_on && j + 1 < E) pfv = pfp[(size_t)(j + 1) * 128];
-#endif
                                 if (odd && S > 32 && (j & 31) == 0) {
 #pragma unroll
                                     for (int m = 0; m < 8; ++m) cw8[m] = cwp[(size_t)((j + m * E) >> 5) * 64];
@@ -698,11 +675,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                                 }
                                 // (issuing the next pass's loads here, ahead of the 15 stores, was measured: -15 % — the
                                 // double-buffered inputs do not fit the 128-VGPR budget)
-#ifdef POLAR_EXPERIMENT_FAKE_ST      // (measurement-only build: the stores of a pass land on the rows of its first iteration)
-                                const int js = 0;
-#else
                                 const int js = j;
-#endif
                                 typedef std::integral_constant<bool, (GM & 1) != 0> G0; typedef std::integral_constant<bool, (GM & 2) != 0> G1;
                                 typedef std::integral_constant<bool, (GM & 4) != 0> G2; typedef std::integral_constant<bool, (GM & 8) != 0> G3;
                                 typedef std::integral_constant<bool, (NT & 2) != 0> N0; typedef std::integral_constant<bool, (NT & 4) != 0> N1;
@@ -1024,9 +997,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     // a leaf the host marked as weak (control word bit 8: no construction for an ordinary channel leaves it
                     // unfrozen) that comes out below 1e-8: the reference decides on the rounding noise of its own arithmetic
                     // there, which the LLR-domain kernel follows much further down than this one -> fallback pass
-#ifndef POLAR_NO_WEAK_GUARD
                     if (POLAR_UNLIKELY2(ctl & 0x100u)) guard |= __ballot(active && fabs(leaf) > 0.99999999 && fabs(leaf) <= 1.0);
-#endif
                 }
                 if (active) {
                     gm = pm + sneg;
@@ -1046,14 +1017,14 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     fast = ((__ballot(ok) | ~group_result_rows<GS>()) == ~0ull);
                 }
                 double gmax = 0.0;
-                if (POLAR_FASTHINT_U(!fast)) {
+                if (!fast) {
                     gmax = group_reduce<GS, true>(gm, lane);
                     const double bmin = group_reduce<GS, false>(bl, lane);
                     fast = wave_all((nact == 0) || (nact == L && gmax < bmin));
                 }
                 PROF_CNT(8, 1)
                 PROF(16)
-                if (POLAR_FASTHINT_L(fast)) {
+                if (fast) {      // (marking this likely — the ranking path out of line — measured -0.5 %)
                     PROF_CNT(9, 1)
 #ifdef POLAR_MARGIN
                     {
