@@ -11,7 +11,8 @@ spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench
 dst = sys.argv[1]
 names = sys.argv[2:]
 KERN = {"config1": "sc8_decode_kernel", "config2": "sc8_decode_kernel", "config2_b262144": "sc8_decode_kernel",
-        "config3": "scl_decode_llr_kernel<4, 3, 0, true", "config5": "scl_decode_llr_kernel<8, 3, 0, true"}
+        "config3": "scl_decode_llr_kernel<4, 3, 0, true", "config5": "scl_decode_llr_kernel<8, 3, 0, true",
+        "config3_b262144": "scl_decode_llr_kernel<4, 3, 0, true", "config5_b262144": "scl_decode_llr_kernel<8, 3, 0, true"}
 h = hashlib.sha256(open(os.path.join(ROOT, "polar_amd", "libpolar_amd.so"), "rb").read()).hexdigest()
 path = os.path.join(ROOT, "profiles", "traffic_configs.json")
 out = {"lib_sha256": h, "configs": {}}
