@@ -17,9 +17,13 @@ CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(ROOT, "include")
 LIB = os.path.join(HERE, "libpolar_amd.so")
 BUILD = os.path.join(HERE, "_build")
-# (source, extra -D, object tag): polar_kernels.hip is compiled twice — LLR-domain and exp-domain kernel families
-SOURCES = [("polar_kernels.hip", ["POLAR_ED_TU=0"], ""), ("polar_kernels.hip", ["POLAR_ED_TU=1"], ".ed"),
-           ("polar_kernels_sc.hip", [], ""), ("polar_kernels_p1.hip", [], ""), ("polar_channel.hip", [], ""), ("polar_construct.hip", [], ""), ("polar_host.cpp", [], "")]
+# (source, extra -D, object tag, extra compiler options): polar_kernels.hip is compiled three times — LLR-domain kernel family,
+# exp-domain kernels of the small groups, exp-domain list of 32 (the headline kernel, with its own scheduler options)
+FLAGS_LIST32 = ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause", "-mllvm", "-amdgpu-use-amdgpu-trackers"]
+SOURCES = [("polar_kernels.hip", ["POLAR_ED_TU=0"], "", []), ("polar_kernels.hip", ["POLAR_ED_TU=1"], ".ed", []),
+           ("polar_kernels.hip", ["POLAR_ED_TU=2"], ".ed32", FLAGS_LIST32),
+           ("polar_kernels_sc.hip", [], "", []), ("polar_kernels_p1.hip", [], "", []), ("polar_channel.hip", [], "", []),
+           ("polar_construct.hip", [], "", []), ("polar_host.cpp", [], "", [])]
 ARCH = "gfx950"
 
 
@@ -102,7 +106,7 @@ def build(force=False, verbose=False, profile=False, bless=False):
               [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     objs = []
     jobs = []
-    for s, defs, otag in SOURCES:
+    for s, defs, otag, xflags in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(BUILD, s + otag + tag + ".o")
         objs.append(obj)
@@ -113,7 +117,7 @@ def build(force=False, verbose=False, profile=False, bless=False):
             cmd.insert(1, "-DPOLAR_PROFILE")
         for d in defs + os.environ.get("POLAR_DEFS", "").split():
             cmd.insert(1, "-D" + d)
-        cmd[1:1] = os.environ.get("POLAR_HIPCC_FLAGS", "").split()    # A/B experiments with compiler options
+        cmd[1:1] = xflags + os.environ.get("POLAR_HIPCC_FLAGS", "").split()    # (+ A/B experiments with compiler options)
         fp = _fingerprint(cmd, [src] + _deps(obj, headers))
         stamp = obj + ".sha"
         have = open(stamp).read().strip() if os.path.exists(stamp) and os.path.exists(obj) else None
