@@ -24,7 +24,7 @@ SOURCES = [("polar_kernels.hip", ["POLAR_ED_TU=0"], "", []), ("polar_kernels.hip
            ("polar_kernels.hip", ["POLAR_ED_TU=2"], ".ed32", FLAGS_LIST32),
            ("polar_kernels_sc.hip", [], "", []), ("polar_kernels_p1.hip", [], "", []), ("polar_channel.hip", [], "", []),
            ("polar_construct.hip", [], "", []), ("polar_host.cpp", [], "", [])]
-ARCH = "gfx950"
+ARCH = os.environ.get("POLAR_ARCH", "gfx950")      # (A/B: e.g. gfx950:xnack-)
 
 
 def _hipcc():
