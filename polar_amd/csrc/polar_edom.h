@@ -102,12 +102,27 @@ __device__ __forceinline__ double ed_div(double num, double den) {
     return __builtin_fma(e2, r, q);
 }
 __device__ __forceinline__ double ed_with_sign(double r, int signword) {     // r >= 0
+#ifndef POLAR_NO_SIGN_ASM   // one v_and_or_b32 (the compiler often emits v_and + v_or with a literal)
+    int hi; asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(signword), "s"(0x80000000u), "v"(__double2hiint(r)));
+    return __hiloint2double(hi, __double2loint(r));
+#else
     return __hiloint2double(__double2hiint(r) | (signword & (int)0x80000000), __double2loint(r));
+#endif
 }
+// max / min of the MAGNITUDES as single instructions with |.| source modifiers. Written through the builtins the compiler puts a
+// canonicalising v_max_f64 x, x in front of each operand (IEEE mode: maxnum must quiet signalling NaNs) — two more VALU
+// instructions per pair, on values that are never NaN here (finite stored forms; non-finite channel values are flagged before).
+#ifndef POLAR_NO_ABSMAX_ASM
+__device__ __forceinline__ double ed_absmax(double a, double b) { double r; asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double ed_absmin(double a, double b) { double r; asm("v_min_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#else
+__device__ __forceinline__ double ed_absmax(double a, double b) { return __builtin_fmax(fabs(a), fabs(b)); }
+__device__ __forceinline__ double ed_absmin(double a, double b) { return __builtin_fmin(fabs(a), fabs(b)); }
+#endif
 // f-node. `guard` collects (as a wave mask) the lanes whose |x| < 40 decision is too close to call.
 __device__ __forceinline__ double f_node_e(double a, double b, u64 &guard) {
     const double fa = fabs(a), fb = fabs(b);
-    const double mx = __builtin_fmax(fa, fb), mn = __builtin_fmin(fa, fb);
+    const double mx = ed_absmax(a, b), mn = ed_absmin(a, b);
     const double q = ed_div(fa + fb, __builtin_fma(fa, fb, 1.0));
     const u64 m_hi = __builtin_amdgcn_fcmp(mn, ED_C40_HI, 2);            // mn > e^-40 (1 + 1e-10): certainly |x| < 40
     const u64 m_lo = __builtin_amdgcn_fcmp(mn, ED_C40_LO, 2);
@@ -128,11 +143,11 @@ __device__ __forceinline__ double f_node_e(double a, double b, u64 &guard) {
 // allocator keeps in a VGPR pair (two more VALU instructions per node).
 __device__ __forceinline__ double f_node_e_acc(double a, double b, double &gacc) {
     const double fa = fabs(a), fb = fabs(b);
-    const double mx = __builtin_fmax(fa, fb), mn = __builtin_fmin(fa, fb);
+    const double mx = ed_absmax(a, b), mn = ed_absmin(a, b);
     const double q = ed_div(fa + fb, __builtin_fma(fa, fb, 1.0));
     const u64 m_hi = __builtin_amdgcn_fcmp(mn, ED_C40_HI, 2);            // mn > e^-40 (1 + 1e-10): certainly |x| < 40
     const u64 m_l = __builtin_amdgcn_fcmp(mx, 1.0, 2);                   // an L-form input (rare)
-    gacc = __builtin_fmin(gacc, fabs(mn - ED_C40_HI));
+    gacc = ed_absmin(gacc, mn - ED_C40_HI);
     double r = __builtin_amdgcn_inverse_ballot_w64(m_hi) ? q : mx;
     if (POLAR_UNLIKELY(m_l != 0)) r = __builtin_amdgcn_inverse_ballot_w64(m_l) ? mn : r;
     return ed_with_sign(r, __double2hiint(a) ^ __double2hiint(b));
@@ -169,15 +184,19 @@ __device__ __forceinline__ double g_node_e_rare(double a, double b, int ha, int 
 // g-node: (1-2u) a + b; `usign` carries u in bit 31 (the other bits are ignored)
 __device__ __forceinline__ double g_node_e(double a, double b, unsigned usign, const Tabs &tb) {
     const int ha = __double2hiint(a) ^ (int)usign, hb = __double2hiint(b);      // only the sign bits of ha/hb are used
-    const bool same = (int)(ha ^ hb) >= 0;
+    // (the sign test as a wave mask straight from the compare: through a bool the compiler materialises 0/1 in a VGPR and
+    // compares it again for the ballot below — two VALU instructions per node)
+    const u64 m_same = __builtin_amdgcn_sicmp((int)(ha ^ hb), 0, 39);      // ICMP_SGE: signs equal after (1 - 2u)
+    const bool same = __builtin_amdgcn_inverse_ballot_w64(m_same);
     const double p = fabs(a) * fabs(b);
-    const double lo = __builtin_fmin(fabs(a), fabs(b)), hi = __builtin_fmax(fabs(a), fabs(b));
+    const double lo = ed_absmin(a, b), hi = ed_absmax(a, b);
     const double q = ed_div(lo, hi);                      // == 1.0 exactly when |a| == |b| (b - a = 0)
     const double r = same ? p : q;
     int sg = (fabs(a) < fabs(b)) ? ha : hb;               // opposite signs: the larger |x| (smaller E) decides
-    sg = same ? hb : sg;
+    sg = same ? hb : sg;                                  // (redundant — equal signs: either input's — but without it the headline
+                                                          //  kernel measured 0.5 .. 1.5 % slower: instruction layout, not arithmetic)
     double res = ed_with_sign(r, sg);
-    const u64 m_rare = __builtin_amdgcn_fcmp(hi, 1.0, 2) | __builtin_amdgcn_ballot_w64(same && p < ED_EMIN);
+    const u64 m_rare = __builtin_amdgcn_fcmp(hi, 1.0, 2) | (m_same & __builtin_amdgcn_fcmp(p, ED_EMIN, 4));      // OGT; OLT
     if (POLAR_UNLIKELY(m_rare != 0)) {
         const double sl = g_node_e_rare(a, b, ha, hb, tb.T);
         if (__builtin_amdgcn_inverse_ballot_w64(m_rare)) res = sl;

@@ -270,11 +270,11 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     if (WPB > 1) __syncthreads();
     const Tabs tb = {tabs, tabs + 64, tabs + 64 + 129};
     u64 guard = 0;                                  // (ED) wave mask of lanes with an undecidable |x| < 40 test
-#ifdef POLAR_GMIN
+#ifndef POLAR_NO_GMIN
     double gacc = __builtin_inf();                  // (ED) per lane: smallest distance of a node's smaller E to the |x| < 40 threshold
 #endif
     auto FN = [&](double a, double b) -> double {
-#ifdef POLAR_GMIN
+#ifndef POLAR_NO_GMIN
         if constexpr (ED) return f_node_e_acc(a, b, gacc); else return f_node(a, b, tb);
 #else
         if constexpr (ED) return f_node_e(a, b, guard); else return f_node(a, b, tb);
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         const bool valid = (cwi < Bv);
         const long cw = (p.cw_list && valid) ? (long)p.cw_list[cwi] : cwi;   // codeword (row of llr / out)
         guard = 0;
-#ifdef POLAR_GMIN
+#ifndef POLAR_NO_GMIN
         gacc = __builtin_inf();
 #endif
         auto cw_of_lane = [&](int ln) -> size_t {
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
             return p.cw_list ? (size_t)p.cw_list[i < Bv ? i : Bv - 1] : (size_t)i;     // (lanes past the end of the work list: any valid row)
         };
         auto FN2 = [&](double a0_, double b0_, double a1_, double b1_, double &r0_, double &r1_) {
-#ifdef POLAR_GMIN
+#ifndef POLAR_NO_GMIN
             if constexpr (ED) { r0_ = f_node_e_acc(a0_, b0_, gacc); r1_ = f_node_e_acc(a1_, b1_, gacc); }
 #else
             if constexpr (ED) { r0_ = f_node_e(a0_, b0_, guard); r1_ = f_node_e(a1_, b1_, guard); }
@@ -1377,7 +1377,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         }
         if constexpr (ED) {
             // codewords with an undecidable |x| < 40 test go to the LLR-domain kernel (host: fallback pass)
-#ifdef POLAR_GMIN
+#ifndef POLAR_NO_GMIN
             guard |= __ballot(gacc <= ED_GACC_FLAG);
 #endif
             if (valid && lig == 0 && ((guard >> gbase) & gmask) != 0) p.flags[cw] = 1;
