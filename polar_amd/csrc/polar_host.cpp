@@ -82,6 +82,7 @@ struct polar_code {
     std::vector<uint32_t> ctl;       // [N] frozen | sched << 1 | weak-unfrozen-leaf << 8
     int weak_leaves = 0;             // unfrozen leaves no construction for an ordinary channel would leave unfrozen (derive_tables)
     std::vector<uint32_t> sc_ops;    // schedule of the list-size-1 kernel (PolarScParams::ops)
+    bool sc_fold = false;            //   its top-layer visits read the caller's rows in place (derive_tables)
     // device
     bool dev_ready = false;
     int device = -1, num_cu = 0;
@@ -201,6 +202,14 @@ int derive_tables(polar_code *h) {
             fused.push_back(op);
         }
         h->sc_ops.swap(fused);
+        // The two visits of the top layer read the caller's rows in place (no permuted copy of the batch, no front pass)
+        // when both are depth-3 chains into HBM-resident layers and nothing else touches the channel values.
+        h->sc_fold = h->n >= polar_sc8_fold_min_log();
+        for (uint32_t op : h->sc_ops) {
+            const int type = (int)(op & 7u), sh = (int)((op >> 3) & 15u), extra = (int)((op >> 24) & 3u);
+            if (sh == h->n) h->sc_fold = false;
+            if (type <= 1 && sh == h->n - 1 && extra != 2) h->sc_fold = false;
+        }
     }
     h->ctl.resize(N);
     for (int i = 0; i < N; ++i) h->ctl[i] = (uint32_t)(h->frozen[i] ? 1u : 0u) | ((uint32_t)h->sched[i] << 1);
@@ -554,7 +563,8 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
         // (measured and dropped: as many waves as make the rounds of eight-codeword groups whole — 4 096 instead of 5 120 for
         // 65 536 codewords — is 2.5 % SLOWER: the kernel wants the latency hiding of 20 waves per CU more than a full last round)
         const int sgrid = (int)std::min<long>(groups8, (long)h->num_cu * polar_sc8_waves_per_cu(h->N));
-        if ((rc = h->d_ech.ensure((size_t)B * h->N))) return rc;
+        const bool fold = h->sc_fold && !getenv("POLAR_SC_NO_FOLD");      // (the variable: A/B measurements and the parity tests of both paths)
+        if (!fold && (rc = h->d_ech.ensure((size_t)B * h->N))) return rc;
         if ((rc = h->d_flags.ensure((size_t)B))) return rc;
         if ((rc = h->d_list.ensure((size_t)B))) return rc;
         if ((rc = h->d_count.ensure(1))) return rc;
@@ -565,10 +575,11 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
         HIP_TRY(hipMemsetAsync(h->d_flag_words.p, 0, ((size_t)(B + 31) / 32 + 1) * sizeof(unsigned int), st));
         HIP_TRY(hipMemsetAsync(h->d_count.p, 0, sizeof(unsigned int), st));
         HIP_TRY(hipMemsetAsync(p.work, 0, sizeof(unsigned int), st));
-        HIP_TRY(polar_launch_sc8_front(d_llr, llr_f32, h->d_ech.p, h->d_flag_words.p, h->d_tabs.p, h->n, B, n_dev, st));
+        if (!fold) HIP_TRY(polar_launch_sc8_front(d_llr, llr_f32, h->d_ech.p, h->d_flag_words.p, h->d_tabs.p, h->n, B, n_dev, st));
         PolarScParams sp;
         sp.n = h->n; sp.N = h->N; sp.K = h->K; sp.B = B;
-        sp.ech_t = h->d_ech.p; sp.out = d_out; sp.ops = h->d_sc_ops.p; sp.n_ops = (int)h->sc_ops.size();
+        sp.llr = fold ? d_llr : nullptr; sp.llr_f32 = llr_f32;
+        sp.ech_t = fold ? nullptr : h->d_ech.p; sp.out = d_out; sp.ops = h->d_sc_ops.p; sp.n_ops = (int)h->sc_ops.size();
         sp.order = h->d_order.p; sp.tabs = h->d_tabs.p; sp.a_scr = h->d_llr_scr.p;
         sp.flag_words = h->d_flag_words.p; sp.work = p.work; sp.n_dev = n_dev;
         if (ev_start) HIP_TRY(hipEventRecord((hipEvent_t)ev_start, st));
@@ -1074,7 +1085,7 @@ polar_code *clone_on_device(polar_code *h, int dev, bool fresh = false) {
     c->n = h->n; c->N = h->N; c->K = h->K; c->crc = h->crc; c->eps = h->eps;
     c->frozen = h->frozen; c->order = h->order; c->bitrev = h->bitrev; c->crcm = h->crcm;
     c->W = h->W; c->info_rank = h->info_rank; c->crc_mask = h->crc_mask; c->sched = h->sched; c->ctl = h->ctl;
-    c->sc_ops = h->sc_ops; c->weak_leaves = h->weak_leaves;
+    c->sc_ops = h->sc_ops; c->sc_fold = h->sc_fold; c->weak_leaves = h->weak_leaves;
     c->device = dev;
     c->waves_per_cu = h->waves_per_cu; c->lds_log = h->lds_log; c->pipe = h->pipe; c->prefix_on = h->prefix_on; c->mode = h->mode;
     h->clones.push_back(c);

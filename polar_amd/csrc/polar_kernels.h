@@ -61,7 +61,9 @@ hipError_t polar_launch_sc_p1(const PolarScP1Params &p, int grid, hipStream_t st
 struct PolarScParams {
     int n, N, K;
     long B;
-    const double *ech_t;         // [B][N] device: channel values, stored form, kernel element order (sc8_front_kernel)
+    const double *ech_t;         // [B][N] device: channel values, stored form, kernel element order (sc8_front_kernel); unused when `llr` is set
+    const void *llr;             // nullptr, or [B][N] device: the caller's rows (double, or float when llr_f32), read IN PLACE by the two
+    int llr_f32;                 //   visits of the top layer (no front pass): polar_sc8_can_fold() says for which schedules
     uint8_t *out;                // [B][K] device
     const uint32_t *ops;         // [n_ops] device: schedule words = type | log2(S) << 3 | first leaf << 8
     int n_ops;                   //   type 0 F, 1 G, 3 all-unfrozen, 4 combine, 6 all-frozen bound
@@ -77,6 +79,7 @@ size_t polar_sc8_lds_bytes(int N);
 int polar_sc8_waves_per_block();
 int polar_sc8_waves_per_cu(int N);
 size_t polar_sc8_scratch_doubles_per_wave(int N);
+int polar_sc8_fold_min_log();            // smallest log2(block length) whose top-layer visits can read the caller's rows in place
 int polar_sc8_min_global_log();          // log2 of the smallest HBM-resident layer of the list-size-1 kernel
 hipError_t polar_launch_sc8_front(const void *llr, int llr_f32, double *ech_p, unsigned int *flag_words, const double *tabs,
                                   int n, long B, const unsigned *n_dev, hipStream_t st);

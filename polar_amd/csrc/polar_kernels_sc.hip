@@ -180,9 +180,17 @@ __global__ __launch_bounds__(64 * SC8_WPB) void sc8_decode_kernel(PolarScParams 
                     // layers are still written (their G visits read them later) but not read back (every visit of an
                     // HBM-resident layer is bandwidth: 62 GB per 262 144 codewords at 5.4 TB/s before this).
                     // One iteration = one row of the LAST layer of the chain = 2^(D-1) row pairs of the source.
-                    auto visit_chain = [&](const double *src, size_t sstr, auto depth, auto last_on_chip) {
+                    // top = true (depth 3 only): the source is the CHANNEL, read where the caller put it. Element e of the kernel's
+                    // order is channel position bitrev_n(e); the eight source values of one iteration — rows r + k RS (+ R) — are
+                    // eight CONSECUTIVE channel positions (the three top bits of the row index are the three low bits of the
+                    // position), so a lane reads one whole 64-byte sector (32 B of floats) and no permuted copy of the batch is
+                    // ever written: sc8_front_kernel cost 12 % of the time and 32 KB of traffic per codeword. F converts the
+                    // eight values to stored form; G adds in the LLR domain as the reference does (PolarCode.cpp:449-450) and
+                    // converts its four results.
+                    auto visit_chain = [&](const double *src, size_t sstr, auto depth, auto last_on_chip, auto top_) {
                         constexpr int D = decltype(depth)::value, NP = 1 << (D - 1);
                         constexpr bool LL = decltype(last_on_chip)::value;   // the last layer of the chain is the LDS-resident SC8_SL
+                        constexpr bool TOP = decltype(top_)::value;
                         const int RS = R / NP;                               // rows of the last layer
                         double *d0 = g_a + (size_t)((S - 2 * SC8_SL) / 8) * 64 + lane;
                         double *d1g = g_a + (size_t)((LL && D == 2 ? 0 : S / 2 - 2 * SC8_SL) / 8) * 64 + lane;
@@ -190,15 +198,42 @@ __global__ __launch_bounds__(64 * SC8_WPB) void sc8_decode_kernel(PolarScParams 
                         double *dll = lds + (size_t)sc8_rowbase(SC8_SL) * 64 + lane;
                         for (int r = 0; r < RS; ++r) {
                             double a[NP], b[NP], y[NP];
+                            if constexpr (TOP && D == 3) {
+                                // position = bitrev3(sub) N/8 + bitrev(r) 8 + 4 k0 + 2 k1 + (b ? 1 : 0)
+                                const size_t pos = (size_t)(valid ? cw : 0) * N + (size_t)(__brev((unsigned)sub) >> 29) * (size_t)(N / 8)
+                                                   + (size_t)(__brev((unsigned)r) >> (32 - (p.n - 6))) * 8;
+                                double v[8];
+                                if (p.llr_f32) {
+                                    const float4 *q = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(p.llr) + pos);
+                                    const float4 x0 = q[0], x1 = q[1];
+                                    v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+                                } else {
+                                    const double2 *q = reinterpret_cast<const double2 *>(reinterpret_cast<const double *>(p.llr) + pos);
 #pragma unroll
-                            for (int k = 0; k < NP; ++k) { a[k] = src[(size_t)(r + k * RS) * sstr]; b[k] = src[(size_t)(r + k * RS + R) * sstr]; }
+                                    for (int i = 0; i < 4; ++i) { const double2 x = q[i]; v[2 * i] = x.x; v[2 * i + 1] = x.y; }
+                                }
+                                bool fl = false;          // the input guard of sc8_front_kernel (ed_from_channel)
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) { const double fx = fabs(v[i]); fl |= !(fx < __builtin_inf()) || fx < 1e-9; }
+                                guard |= __builtin_amdgcn_ballot_w64(fl);
+#pragma unroll
+                                for (int k = 0; k < NP; ++k) { a[k] = v[4 * (k & 1) + 2 * (k >> 1)]; b[k] = v[4 * (k & 1) + 2 * (k >> 1) + 1]; }
+                                if (type == 0) {
+#pragma unroll
+                                    for (int k = 0; k < NP; ++k) { a[k] = ed_from_llr(a[k], tb); b[k] = ed_from_llr(b[k], tb); }
+                                }
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < NP; ++k) { a[k] = src[(size_t)(r + k * RS) * sstr]; b[k] = src[(size_t)(r + k * RS + R) * sstr]; }
+                            }
 #pragma unroll
                             for (int k = 0; k < NP; ++k) {
                                 if (type == 0) y[k] = f_node_e(a[k], b[k], guard);
                                 else {
                                     const int j = base + 8 * (r + k * RS) + sub;
                                     const uint32_t w = bw[(size_t)(j >> 5) * 8 + cws];
-                                    y[k] = g_node_e(a[k], b[k], w << (31 - (j & 31)), tb);
+                                    if constexpr (TOP && D == 3) y[k] = ed_from_llr(b[k] + (((w >> (j & 31)) & 1u) ? -a[k] : a[k]), tb);
+                                    else y[k] = g_node_e(a[k], b[k], w << (31 - (j & 31)), tb);
                                 }
                                 d0[(size_t)(r + k * RS) * 64] = y[k];
                             }
@@ -219,14 +254,17 @@ __global__ __launch_bounds__(64 * SC8_WPB) void sc8_decode_kernel(PolarScParams 
                         typedef std::integral_constant<int, 2> D2;
                         typedef std::integral_constant<int, 3> D3;
                         const bool ll = (S >> extra) <= SC8_SL;
-                        if (2 * S == N) {
+                        typedef std::false_type NT;
+                        if (2 * S == N && p.llr) {               // (host: only schedules whose top visits are depth-3 chains into HBM layers)
+                            visit_chain(nullptr, 0, D3(), std::false_type(), std::true_type());
+                        } else if (2 * S == N) {
                             const double *sc = ch + sub;
-                            if (extra == 1) { if (ll) visit_chain(sc, 8, D2(), std::true_type()); else visit_chain(sc, 8, D2(), std::false_type()); }
-                            else { if (ll) visit_chain(sc, 8, D3(), std::true_type()); else visit_chain(sc, 8, D3(), std::false_type()); }
+                            if (extra == 1) { if (ll) visit_chain(sc, 8, D2(), std::true_type(), NT()); else visit_chain(sc, 8, D2(), std::false_type(), NT()); }
+                            else { if (ll) visit_chain(sc, 8, D3(), std::true_type(), NT()); else visit_chain(sc, 8, D3(), std::false_type(), NT()); }
                         } else {
                             const double *sg = g_a + (size_t)((2 * S - 2 * SC8_SL) / 8) * 64 + lane;
-                            if (extra == 1) { if (ll) visit_chain(sg, 64, D2(), std::true_type()); else visit_chain(sg, 64, D2(), std::false_type()); }
-                            else { if (ll) visit_chain(sg, 64, D3(), std::true_type()); else visit_chain(sg, 64, D3(), std::false_type()); }
+                            if (extra == 1) { if (ll) visit_chain(sg, 64, D2(), std::true_type(), NT()); else visit_chain(sg, 64, D2(), std::false_type(), NT()); }
+                            else { if (ll) visit_chain(sg, 64, D3(), std::true_type(), NT()); else visit_chain(sg, 64, D3(), std::false_type(), NT()); }
                         }
                         wave_mem_fence();
                         continue;
@@ -384,6 +422,8 @@ __global__ __launch_bounds__(64 * SC8_WPB) void sc8_decode_kernel(PolarScParams 
 }
 size_t polar_sc8_lds_bytes(int N) { return 324 * 8 + (size_t)SC8_WPB * ((size_t)SC8_ROWS * 64 * 8 + (size_t)((N + 31) / 32) * 8 * 4); }
 int polar_sc8_waves_per_block() { return SC8_WPB; }
+// folding needs: n - 6 >= 1 row-index bits below the chain's three, and the chain's last layer (N/8) HBM-resident
+int polar_sc8_fold_min_log() { int l = 7; while ((1 << l) / 8 < 2 * SC8_SL) ++l; return l; }
 int polar_sc8_min_global_log() { int l = 0; while ((1 << l) < 2 * SC8_SL) ++l; return l; }
 int polar_sc8_waves_per_cu(int N) { const int w = (int)((160 * 1024) / polar_sc8_lds_bytes(N)) * SC8_WPB; return w > 32 ? 32 : w; }
 size_t polar_sc8_scratch_doubles_per_wave(int N) { return sc8_scratch_doubles(N); }

@@ -301,7 +301,32 @@ def test_long_codes_and_extreme_parameters(built_lib, oracle_built, n, K, crc, L
     assert (want == got).all()
 
 
-@pytest.mark.parametrize("n,K,crc,L", [(9, 256, 8, 8), (11, 1024, 16, 32), (6, 20, 3, 1)])
+@pytest.mark.parametrize("n,K,crc", [(9, 256, 8), (10, 512, 0), (11, 1024, 16), (13, 4096, 0)])
+def test_list_size_one_reads_the_callers_rows_in_place(built_lib, oracle_built, n, K, crc, monkeypatch):
+    """From N = 512 on the two top-layer visits of the L = 1 kernel read the caller's rows where they lie (bit-reversed
+    64-byte chunks, converted on the fly; the G visit adds in the LLR domain) instead of a permuted, converted copy made
+    by a front pass. Both paths must give the reference's bits, including rows the input guard sends to the general kernel."""
+    import polar_amd
+    o, g = _pair(n, K, crc)
+    B = 203                                      # ragged: not a multiple of the eight codewords per wave
+    llr, _ = o.synth_llr(818, 0, B, o.snr_sqrt_linear(1.0))
+    llr[3, 5] = 0.0
+    llr[4, 100] = np.inf
+    llr[5] *= 1e-12
+    llr[6, : 1 << (n - 1)] = 800.0               # L-form values through the top G visit
+    llr[7] = -llr[7]
+    want = o.decode_scl_llr(llr, 1)
+    got = g.decode_scl_llr(llr, 1)
+    monkeypatch.setenv("POLAR_SC_NO_FOLD", "1")
+    got_front = g.decode_scl_llr(llr, 1)
+    monkeypatch.delenv("POLAR_SC_NO_FOLD")
+    assert (got == want).all() and (got_front == want).all()
+    f = llr.astype(np.float32)
+    want32 = o.decode_scl_llr(f.astype(np.float64), 1)
+    assert (g.decode_scl_llr(f, 1) == want32).all()
+
+
+@pytest.mark.parametrize("n,K,crc,L", [(9, 256, 8, 8), (11, 1024, 16, 32), (6, 20, 3, 1), (11, 1024, 16, 1)])
 def test_float32_llr_boundary(built_lib, oracle_built, n, K, crc, L):
     """the boundary also takes single-precision LLRs; they are widened exactly, so the
     result is the reference's decode of (double)llr."""
