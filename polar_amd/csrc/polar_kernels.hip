@@ -172,8 +172,9 @@ __device__ __forceinline__ void softplus_pair(double a, bool skip, const Tabs &t
 
 // leaf terms for the path metric. LLR-domain kernel: `leaf` is the LLR; E-domain: stored form.
 //   neg  = (llr < 0);  al = |llr|;  sneg = log(1+e^-|llr|);  spos = log(1+e^|llr|)
+// actw: the wave mask of `active` (kept by the caller: a ballot of a compound bool costs a round trip through a VGPR)
 template <bool ED>
-__device__ __forceinline__ void leaf_terms(double leaf, bool active, const Tabs &tb, bool &neg, double &al, double &sneg, double &spos) {
+__device__ __forceinline__ void leaf_terms(double leaf, bool active, u64 actw, const Tabs &tb, bool &neg, double &al, double &sneg, double &spos) {
     if (!ED) {
         al = fabs(leaf);
         neg = leaf < 0;
@@ -185,13 +186,22 @@ __device__ __forceinline__ void leaf_terms(double leaf, bool active, const Tabs 
         const bool isl = m > 1.0;
         neg = (__double2hiint(leaf) < 0) && m != 1.0;
         al = m;
+#ifndef POLAR_NO_ACTW
+        const u64 m_e = actw & __builtin_amdgcn_fcmp(m, 1.0, 13);           // ULE: active lanes holding an E-form value
+        if (POLAR_LIKELY2(m_e != 0)) {
+#else
         if (POLAR_LIKELY2(wave_any(active && !isl))) {
+#endif
             const double l = -ed_log(__builtin_fmin(__builtin_fmax(m, ED_EMIN), 1.0), tb);
             if (!isl) al = l;
         }
         const double onep = 1.0 + m;                 // == 1 exactly from E <= 2^-53 on, as the reference's 1 + e^-|x|
         sneg = 0.0;
+#ifndef POLAR_NO_ACTW
+        if (POLAR_LIKELY2((m_e & __builtin_amdgcn_fcmp(onep, 1.0, 14)) != 0)) {      // UNE
+#else
         if (POLAR_LIKELY2(wave_any(active && !isl && onep != 1.0))) {
+#endif
             const double h = log_1p2(__builtin_fmin(onep, 2.0), tb);
             if (!isl) sneg = h;
         }
@@ -335,6 +345,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         // initializeDataStructures + assignInitialPath (PolarCode.cpp:195-272): the inactive
         // stack holds 0..L-1, the first pop (initial path) is L-1.
         bool active = valid && (lig == L - 1);
+        u64 actw = __ballot(active);               // wave mask of `active`, refreshed where it changes (initial path, kill / clone)
         double pm = 0.0;
         int sp = L - 1;                            // group-uniform stack pointer
         if (lig < L - 1) stackv[gbase + lig] = (unsigned char)lig;
@@ -926,7 +937,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         bool ng; double alz, sneg, spos;
-                        leaf_terms<ED>(lf[i], active, tb, ng, alz, sneg, spos);
+                        leaf_terms<ED>(lf[i], active, actw, tb, ng, alz, sneg, spos);
                         if (active) pm += ng ? spos : sneg;
                     }
                 };
@@ -976,11 +987,11 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 // continuePaths_FrozenBit: PolarCode.cpp:475-487
                 // PM += log(1+e^-llr): exactly 0 for llr >= 37, exactly |llr| (+0) for llr <= -37
                 bool ng; double alz, sneg, spos;
-                leaf_terms<ED>(leaf, active, tb, ng, alz, sneg, spos);
+                leaf_terms<ED>(leaf, active, actw, tb, ng, alz, sneg, spos);
                 if (active) pm += ng ? spos : sneg;
             } else {
                 // continuePaths_UnfrozenBit: PolarCode.cpp:489-607
-                const u64 actm = (__ballot(active) >> gbase) & gmask;
+                const u64 actm = (actw >> gbase) & gmask;
                 const int nact = __popcll(actm);
                 const int rho = (2 * nact < L) ? 2 * nact : L;
                 // ---- fast path (exact): list full and every "good" fork (the bit the leaf LLR favours)
@@ -992,7 +1003,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 double sneg, spos;                         // log(1+e^-|llr|), log(1+e^|llr|)
                 // (a logarithm-free lower bound of |llr| for this test — exponent and mantissa of E — was measured:
                 // -1.5 %, the bound is short by up to 0.06 and sends more steps down the ranking path)
-                leaf_terms<ED>(leaf, active, tb, lneg, al, sneg, spos);
+                leaf_terms<ED>(leaf, active, actw, tb, lneg, al, sneg, spos);
                 if constexpr (ED) {
                     // a leaf the host marked as weak (control word bit 8: no construction for an ordinary channel leaves it
                     // unfrozen) that comes out below 1e-8: the reference decides on the rounding noise of its own arithmetic
@@ -1013,8 +1024,13 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     unsigned gh = active ? (unsigned)__double2hiint(gm) : 0u;
                     unsigned bh = active ? (unsigned)__double2hiint(bl) : 0xFFFFFFFFu;
                     group_max_min_u32<GS>(gh, bh);
+#ifndef POLAR_NO_ACTW
+                    const u64 m_ok = __builtin_amdgcn_sicmp(nact, 0, 32) | (__builtin_amdgcn_sicmp(nact, L, 32) & __builtin_amdgcn_uicmp(gh, bh, 36));   // EQ, EQ, ULT
+                    fast = ((m_ok | ~group_result_rows<GS>()) == ~0ull);
+#else
                     const bool ok = (nact == 0) || (nact == L && gh < bh);
                     fast = ((__ballot(ok) | ~group_result_rows<GS>()) == ~0ull);
+#endif
                 }
                 double gmax = 0.0;
                 if (!fast) {
@@ -1068,7 +1084,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                         // group; those are peeled off by a DPP maximum over the metrics' high words (non-negative
                         // doubles order like their bit patterns), all lanes sharing the maximal high word at once
                         // when k allows, otherwise the low words and lane numbers decide, on the scalar unit.
-                        const u64 actm64 = __ballot(active);
+                        const u64 actm64 = actw;
                         const u64 gbm = __ballot(goodbit);
                         u64 surv = 0;
                         PROF_CNT(10, 1)
@@ -1268,6 +1284,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     }
                 }
                 active = (active && !kill) || is_clone;
+                actw = __ballot(active);
                 if (active) {
                     pm = pm_new;
                     hword |= ubit << (t & 31);
@@ -1538,7 +1555,7 @@ __global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p, int st
         for (int r = 0; r < 8; ++r) {
             if (r < R && r * 32 < Pe) {
                 bool ng; double al, sneg, spos;
-                leaf_terms<ED>(x[r], true, tb, ng, al, sneg, spos);
+                leaf_terms<ED>(x[r], true, __builtin_amdgcn_ballot_w64(true), tb, ng, al, sneg, spos);
                 const double spv = ng ? spos : sneg;
                 const int cnt = (Pe - r * 32 < 32) ? (Pe - r * 32) : 32;
                 // (the sum must run in leaf order; unrolled, the 32 cross-lane reads are in flight together and only the

@@ -19,4 +19,5 @@ FUZZ_SANE=1 python tools/fuzz_parity.py 300 11 > $O/fuzz_sane.txt 2>&1
 python tools/fuzz_parity.py 150 12 > $O/fuzz_any.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 tools/mall_microbench.hip -o /tmp/mb 2>/dev/null && /tmp/mb > $O/cache_footprint_microbench.txt
 python tools/mc_rate.py 32 1048576 > $O/mc_rate.txt 2>&1
+python tools/sc_rounds.py $O/sc_rounds.json > $O/sc_rounds.txt 2>&1
 cat $O/gpu_tests.txt; tail -c 400 $O/bench_b524288.json; tail -2 $O/stress_parity.txt $O/fuzz_sane.txt $O/fuzz_any.txt $O/mc_rate.txt
