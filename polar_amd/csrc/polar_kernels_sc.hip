@@ -196,7 +196,10 @@ __global__ __launch_bounds__(64 * SC8_WPB) void sc8_decode_kernel(PolarScParams 
                         double *d1g = g_a + (size_t)((LL && D == 2 ? 0 : S / 2 - 2 * SC8_SL) / 8) * 64 + lane;
                         double *d2g = g_a + (size_t)((LL || D < 3 ? 0 : S / 4 - 2 * SC8_SL) / 8) * 64 + lane;
                         double *dll = lds + (size_t)sc8_rowbase(SC8_SL) * 64 + lane;
-                        for (int r = 0; r < RS; ++r) {
+                        for (int it = 0; it < RS; ++it) {
+                            // (top: rows r and r + RS/2 are the two 64-byte halves of one 128-byte line — visited back to back, the
+                            // second half is an L2 hit instead of a second fetch of the line)
+                            const int r = (TOP && D == 3) ? (it >> 1) + (it & 1) * (RS / 2) : it;
                             double a[NP], b[NP], y[NP];
                             if constexpr (TOP && D == 3) {
                                 // position = bitrev3(sub) N/8 + bitrev(r) 8 + 4 k0 + 2 k1 + (b ? 1 : 0)

@@ -9,7 +9,11 @@ import shutil
 import sys
 
 src, dst, note = sys.argv[1], sys.argv[2], sys.argv[3]
-kern = sys.argv[4] if len(sys.argv) > 4 else "scl_decode"
+kern = sys.argv[4] if len(sys.argv) > 4 else None
+if kern is None:
+    # the dominant decode kernel of the trace (the fallback pass launches a second, tiny, instantiation whose name also matches)
+    rows = [r for r in csv.DictReader(open(f"{src}/trace/trace_kernel_stats.csv")) if "scl_decode" in r["Name"] or "sc8_decode" in r["Name"]]
+    kern = max(rows, key=lambda r: float(r["TotalDurationNs"]))["Name"].split("(")[0]
 shutil.copy(f"{src}/trace/trace_kernel_stats.csv", dst + "_kernel_stats.csv")
 out = {}
 for f in sorted(glob.glob(f"{src}/pmc*/pmc_counter_collection.csv")):
