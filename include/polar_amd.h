@@ -207,7 +207,10 @@ int polar_set_tuning(polar_code_t *h, int waves_per_cu, int lds_log);
  * other arithmetic reproduces bit for bit: the handle marks such leaves at creation (BEC(1/2) capacity below 1e-3) and every
  * codeword in which one of them comes out below 1e-8 is decoded by the LLR-domain kernel whatever the mode, so automatic
  * mode is never worse there than mode 1 (DESIGN.md "Where bit-exactness ends"; tests/test_gpu_fuzz.py). With list sizes
- * below 3 mode 2 falls back to the LLR-domain kernel (the exp-domain kernels exist for groups of 4 lanes and more). */
+ * below 3 mode 2 falls back to the LLR-domain kernel (the exp-domain kernels exist for groups of 4 lanes and more).
+ * Environment overrides read at every decode (measurement and tests only): POLAR_MODE=<0|1|2> replaces the handle's mode;
+ * POLAR_SC_NO_FOLD=1 makes the list-size-1 kernel decode a permuted, converted copy of the batch (its round-2 front pass)
+ * instead of reading the caller's rows in place. Results do not depend on either. */
 int polar_set_mode(polar_code_t *h, int mode);
 /* test hook: how many unfrozen leaves the handle classified as weak at creation (BEC(1/2) capacity below 1e-3; see above) */
 int polar_debug_weak_leaves(const polar_code_t *h);
