@@ -10,6 +10,13 @@ before the timed region (inputs resident in HBM). A "step" = one pass of the hot
 batch: decode `batch` codewords per GPU + count block errors. Multi-GPU = Monte-Carlo trial
 sharding (rank r owns its own trial range, no data-path collective); the error/run counters are
 all-reduced (RCCL, uint64 sum) once inside the timed region. Scaling is weak (per-GPU batch fixed).
+
+Second leg, same line ("monte_carlo"): the END-TO-END path north_star shards — PolarCode::get_bler_quick
+(PolarCode.cpp:658-785) over BASELINE configuration 4's grid (Eb/N0 1:0.25:2 dB, L=32 + CRC16), a FIXED total number of
+trials (strong scaling), rounds of 262144 trials per GPU, one counter all-reduce per round — through both drivers: the
+multi-process one (polar_amd/montecarlo.py, one rank per GPU, torch.distributed all-reduce) and the native one
+(polar_get_bler_quick_multi_ex from rank 0, one worker thread per GPU, ncclAllReduce) — with `counters_equal_single_gpu`:
+a 65536-trial prefix decoded on ONE GPU must give exactly the sharded counters (counter-based inputs).
 """
 import argparse
 import json
@@ -45,6 +52,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="codewords for the CPU baseline (-1 = auto, 0 = skip)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short timings of BASELINE.json configs 1, 2, 3, 5")
     ap.add_argument("--only-config", default="", help="run ONE of the other configurations (" + ", ".join(OTHER_CONFIGS) + ") and print its record: the command tools/profile_configs.sh profiles")
+    ap.add_argument("--mc-trials", type=int, default=4194304, help="total trials of the end-to-end get_bler_quick leg (0 = skip)")
     ap.add_argument("--dry-run-gloo", action="store_true",
                     help="launcher / rendezvous / counter all-reduce only, on CPU over gloo: no kernel runs, the line carries "
                          "\"dry_run\": true and no throughput (tests/test_bench_launcher.py)")
@@ -228,6 +236,12 @@ def main():
         "note": "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles), committed profile (profiles/traffic.json)",
     }
 
+    if args.mc_trials > 0:
+        del llr, sent
+        res["monte_carlo"] = monte_carlo_leg(args, code, dist, dev, rank, world)
+        llr = torch.empty((B, N), dtype=torch.float64, device=dev)          # (the CPU baseline below re-checks the batch)
+        code.synth_llr_dev(args.seed, trial0, B, s, llr.data_ptr(), 0)
+        torch.cuda.synchronize()
     if rank == 0 and world == 1 and args.cpu_sample != 0:
         res["cpu_baseline"] = cpu_baseline(args, code, llr, out)
     if rank == 0 and world == 1 and not args.no_other_configs:
@@ -238,6 +252,90 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         print(json.dumps(res), flush=True)     # the ONE JSON line, last thing on stdout
+
+
+MC_GRID = [1.0, 1.25, 1.5, 1.75, 2.0]        # BASELINE configuration 4: Eb/N0 1:0.25:2 dB, L = 32 + CRC16
+MC_PREFIX = 65536
+
+
+def monte_carlo_leg(args, code, dist, dev, rank, world, engine=None, native=True):
+    """End-to-end get_bler_quick, strong scaling: args.mc_trials trials in total whatever the world size, rounds of 262144
+    trials per GPU, one all-reduce of the counters per round (PolarCode.cpp:696-775; the early stop of :725 is disabled by
+    max_err so that every world size does the same work). Both drivers, and the sharded counters of a 65536-trial
+    prefix against ONE GPU decoding that prefix alone."""
+    from polar_amd.montecarlo import get_bler_quick_sharded
+    Ls = [args.L]
+    total, per_round = args.mc_trials, 262144 * world
+    no_stop = 10 ** 12
+    if engine is None:
+        engine = code.mc_batch
+
+    def sync():
+        if dev is not None:
+            torch.cuda.synchronize()
+
+    host_group = None
+    if dist is not None and world > 1:
+        host_group = dist.new_group(backend="gloo")          # host-side barriers: no barrier kernel sits on the peers' GPUs
+                                                             # while rank 0 drives all of them through the native entry point
+
+    def hbar():
+        if host_group is not None:
+            dist.barrier(group=host_group)
+
+    def tmax(dt):
+        if dist is None or world == 1:
+            return dt
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=host_group)
+        return float(t.item())
+
+    out = {"workload": f"get_bler_quick N={code.N} K={code.K} crc={args.crc} L={args.L}, Eb/N0 {MC_GRID[0]}:0.25:{MC_GRID[-1]} dB, "
+                       f"{total} trials in total (strong scaling), rounds of 262144 trials per GPU, one counter all-reduce per round, "
+                       f"generation + encoding + channel + decode + counting on the device",
+           "total_trials": total, "n_gpus": world}
+    # ---- multi-process driver (this launch: one rank per GPU)
+    get_bler_quick_sharded(engine, MC_GRID, Ls, max_runs=min(total, per_round), max_err=no_stop, seed=args.seed, global_batch=per_round, device=dev)   # warm-up (allocations)
+    sync(); hbar()
+    st = {}
+    t0 = time.perf_counter()
+    bler, err, run = get_bler_quick_sharded(engine, MC_GRID, Ls, max_runs=total, max_err=no_stop, seed=args.seed, global_batch=per_round, device=dev, stats=st)
+    sync(); hbar()
+    dt = tmax(time.perf_counter() - t0)
+    out["multiprocess"] = {"driver": "polar_amd/montecarlo.py, one rank per GPU, torch.distributed all-reduce per round",
+                           "seconds": dt, "mc_trials_per_s": total / dt, "rounds": st.get("rounds"),
+                           "bler": [float(x) for x in bler[0]], "block_errors": [int(x) for x in err[0]], "runs": [int(x) for x in run[0]]}
+    out["mc_trials_per_s"] = total / dt
+    # ---- the same 65536-trial prefix: sharded over the ranks vs ONE GPU alone (rank 0)
+    _, e_sh, r_sh = get_bler_quick_sharded(engine, MC_GRID, Ls, max_runs=MC_PREFIX, max_err=no_stop, seed=args.seed, global_batch=MC_PREFIX, device=dev)
+    equal = {"multiprocess": None, "native_multi": None}
+    e_one = r_one = None
+    if rank == 0 and native:
+        _, c1 = code.get_bler_quick(MC_GRID, Ls, max_runs=MC_PREFIX, max_err=no_stop, seed=args.seed, batch=MC_PREFIX, return_counters=True)
+        e_one, r_one = c1["err"], c1["run"]
+        equal["multiprocess"] = bool(np.array_equal(e_one, e_sh) and np.array_equal(r_one, r_sh))
+    # ---- native driver: ONE host process (rank 0) drives all the GPUs of the launch (what the C++ / MATLAB hosts call)
+    if rank == 0 and native:
+        try:
+            code.debug_set("multi_timeout_s", 180)
+            devs = list(range(world))
+            code.get_bler_quick(MC_GRID, Ls, max_runs=min(total, per_round), max_err=no_stop, seed=args.seed, batch=per_round, devices=devs)   # warm-up: contexts, communicators
+            t0 = time.perf_counter()
+            b2, c2 = code.get_bler_quick(MC_GRID, Ls, max_runs=total, max_err=no_stop, seed=args.seed, batch=per_round, devices=devs, return_counters=True)
+            dt2 = time.perf_counter() - t0
+            _, c3 = code.get_bler_quick(MC_GRID, Ls, max_runs=MC_PREFIX, max_err=no_stop, seed=args.seed, batch=MC_PREFIX, devices=devs, return_counters=True)
+            equal["native_multi"] = bool(np.array_equal(e_one, c3["err"]) and np.array_equal(r_one, c3["run"]))
+            out["native_multi"] = {"driver": "polar_get_bler_quick_multi_ex from rank 0: one worker thread, stream and table clone per GPU, "
+                                             "ncclAllReduce(uint64, sum) per round" + ("" if code.last_used_rccl else " (host-side sum: RCCL not used)"),
+                                   "seconds": dt2, "mc_trials_per_s": total / dt2, "rounds": c2["rounds"], "used_rccl": bool(code.last_used_rccl),
+                                   "bler": [float(x) for x in b2[0]], "block_errors": [int(x) for x in c2["err"][0]],
+                                   "equals_multiprocess_counters": bool(np.array_equal(c2["err"], err) and np.array_equal(c2["run"], run))}
+        except Exception as ex:                              # (the headline above must be printed whatever happens here)
+            out["native_multi"] = {"error": str(ex)[:500]}
+    hbar()
+    out["counters_equal_single_gpu"] = (None if not native else bool(equal["multiprocess"] and (equal["native_multi"] is not False)))
+    out["counters_equal_single_gpu_detail"] = dict(equal, prefix_trials=MC_PREFIX)
+    return out
 
 
 def dry_run(args, world, rank):
@@ -259,11 +357,42 @@ def dry_run(args, world, rank):
     tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dist.barrier()
+    # the end-to-end Monte-Carlo leg with a stand-in engine (no kernel): trial t is a "block error" at point i when a hash
+    # of (t, i) says so — the rounds, the per-round counter all-reduce, the strided shards and the prefix comparison are real
+    mc = None
+    if args.mc_trials > 0:
+        def engine(seed, t0, T, stride, ebno, Ls, enabled, err, run):
+            t = (np.arange(T, dtype=np.uint64) * np.uint64(stride) + np.uint64(t0))
+            for li in range(len(Ls)):
+                for ie in range(len(ebno)):
+                    if enabled[li, ie]:
+                        h = (t * np.uint64(2654435761) + np.uint64(97 * ie + seed)) % np.uint64(1000)
+                        err[li, ie] += np.uint64(int((h < np.uint64(160 >> ie)).sum()))
+                        run[li, ie] += np.uint64(T)
+
+        class _One:        # the "one GPU alone" side of the prefix check: the same engine, unsharded
+            N, K = 1 << args.n, args.K
+
+            def get_bler_quick(self, grid, Ls, max_runs, max_err, seed, batch, return_counters=True, devices=None):
+                e = np.zeros((len(Ls), len(grid)), np.uint64); r = np.zeros_like(e)
+                engine(seed, 0, max_runs, 1, grid, Ls, np.ones(e.shape, np.uint8), e, r)
+                self.last_used_rccl = False
+                return e / np.maximum(r, 1), {"err": e, "run": r, "rounds": 1}
+
+            def debug_set(self, k, v):
+                pass
+
+        a2 = argparse.Namespace(**vars(args))
+        a2.mc_trials = min(args.mc_trials, 8 * 262144 * world)
+        mc = monte_carlo_leg(a2, _One(), dist, None, rank, world, engine=engine, native=True)
+        if rank == 0:
+            mc["native_multi"] = {"skipped": "dry run: the native driver needs GPUs"}
+            mc["counters_equal_single_gpu_detail"]["native_multi"] = None
     dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"metric": "codewords/s (N=2048 K=1024 L=32 LLR-SCL)", "value": None, "unit": "codewords/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
-                          "runs_all_ranks": int(counters[1]), "scaling": "weak",
+                          "runs_all_ranks": int(counters[1]), "scaling": "weak", "monte_carlo": mc,
                           "config": {"workload": "dry run (gloo, CPU): launcher and counter reduction only"}}), flush=True)
 
 

@@ -8,7 +8,8 @@
  * (INTEGRATION.md shows each binding).
  *
  * Conventions
- *   - all functions return 0 on success, a negative POLAR_E_* code otherwise;
+ *   - all functions return 0 on success, a negative POLAR_E_* code otherwise (one positive, non-error status exists:
+ *     POLAR_W_WEAK_LEAVES from polar_create_explicit);
  *     polar_last_error() returns a thread-local message. No exceptions cross the ABI.
  *   - the caller owns every buffer; the library never retains a pointer past the call.
  *   - "host" entry points take host pointers (H2D/D2H included); "_dev" entry points take
@@ -39,6 +40,8 @@ extern "C" {
 #define POLAR_E_DEVICE (-2)   /* no HIP device / HIP runtime error */
 #define POLAR_E_NOMEM (-3)
 #define POLAR_E_UNSUPPORTED (-4)
+#define POLAR_W_WEAK_LEAVES 1 /* polar_create_explicit only: the handle is valid, but the table leaves unfrozen leaves in the
+                                 worst synthetic channels (see polar_set_mode): bit-exactness with the reference is limited there */
 
 #define POLAR_MAX_N_LOG2 15   /* reference: uint16_t _block_length (PolarCode.h:40) */
 #define POLAR_MAX_LIST 64     /* reference loops forever for L > 127 (uint8_t, PolarCode.cpp:525) */
@@ -94,10 +97,14 @@ int polar_decode_scl_llr_batch_dev(polar_code_t *h, const double *d_llr, long B,
 int polar_decode_scl_llr_batch_f32(polar_code_t *h, const float *llr, long B, int L, uint8_t *out);
 int polar_decode_scl_llr_batch_dev_f32(polar_code_t *h, const float *d_llr, long B, int L, uint8_t *d_out,
                                        double *d_pm, void *stream);
-/* Pre-size the handle's device scratch for decodes of up to B codewords at list size L (runs one decode on generated
- * inputs and waits for it). The device-resident entry points grow their scratch on demand — a hipFree/hipMalloc, i.e. an
- * implicit device synchronisation, whenever B or L exceeds anything seen before; after polar_reserve they do not allocate
- * for calls within (B, L). */
+/* Pre-size the handle's device scratch for decodes of up to B codewords at list sizes 1 .. L (runs one decode per kernel
+ * family on generated inputs — the list-size-1 kernel, the 2-lane groups, every power-of-two lane group up to L, with and
+ * without d_pm — and waits for them). The device-resident entry points grow their scratch on demand — a hipFree/hipMalloc,
+ * i.e. an implicit device synchronisation, whenever B or L exceeds anything seen before; after polar_reserve they do not
+ * allocate for calls of at most B codewords and list size at most L, double or float LLRs, under the handle's current mode and
+ * tuning (tests/test_gpu_parity.py asserts it on the allocation counter, polar_debug_get "allocs").
+ * d_llr needs the natural alignment of its element type; rows that start 16-byte aligned (any hipMalloc'ed batch) let the
+ * list-size-1 kernel read them in place, other pointers are decoded through a converted copy (same results). */
 int polar_reserve(polar_code_t *h, long B, int L);
 /* same, recording two hipEvent_t (may be NULL) on `stream` immediately around the launch of the
  * dominant kernel (scl_decode_llr_kernel), i.e. after the small all-frozen-prefix kernel — for
@@ -149,12 +156,31 @@ int polar_get_bler_quick_ber(polar_code_t *h, const double *ebno, int n_e, const
  * devices[d] (NULL = 0..n_dev-1) simulates the trials d, d + n_dev, ... of every round on its own stream, with its
  * own copy of the code tables and scratch (owned by `h`); the round's counters are summed with one RCCL
  * ncclAllReduce(uint64, sum) over xGMI (bound at run time; a host-side sum when RCCL cannot be loaded, or with
- * POLAR_NO_RCCL set). Counter-based inputs make the result independent of n_dev. *used_rccl (optional) reports
- * which path summed the counters. ber_out may be NULL. A device may be listed once; the test hook POLAR_TEST_SHARE_DEVICE
- * (environment) lifts that so that one GPU can stand in for several (separate contexts and worker threads, host-side sum). */
+ * POLAR_NO_RCCL set when the handle was created). Counter-based inputs make the counters independent of n_dev for a given
+ * `batch` (the automatic rounds grow with the device count: 262144 trials per device). *used_rccl (optional) reports
+ * which path summed the counters. ber_out may be NULL. A device may be listed once; the test hook "share_device"
+ * (polar_debug_set) lifts that so that one GPU can stand in for several (separate contexts and worker threads, host-side
+ * sum). One worker thread per device lives on the handle between calls (created with the communicators). */
 int polar_get_bler_quick_multi(polar_code_t *h, const int *devices, int n_dev, const double *ebno, int n_e,
                                const uint8_t *L, int n_L, long max_runs, long max_err, uint64_t seed, long batch,
                                double *bler_out, double *ber_out, int *used_rccl);
+
+/* General form of the sweep: `constellation` 0 / POLAR_CONST_BPSK = BPSK over AWGN with the Eb/N0 axis of
+ * PolarCode.cpp:744-753 (what the three entry points above simulate); POLAR_CONST_ASK{4,8,16}_GRAY (include/polar_synth.h) =
+ * the ASK Gray + BICM front end of PolarM/Constellation.m with the SNR axis and fresh info bits every run
+ * (PolarM/main_MC_CC_Comparison.m:44-119: BASELINE configuration 5, sharded over the GPUs of the node from one host
+ * process). devices == NULL: 0..n_dev-1 (with n_dev == 1: the handle's own device). Optional outputs (may be NULL):
+ * ber_out, the raw counters err_out / run_out [n_L*n_e] (block errors and simulated-or-counted runs per point: what the
+ * estimates are made of, and what two runs are compared by), *rounds_out = rounds the call took, *used_rccl.
+ * Rounds: `batch` trials over all devices, or (batch == 0) geometric up to 262144 trials PER DEVICE.
+ * Failure handling: a device that fails before the round's collective keeps every device out of it; a device whose
+ * collective enqueue fails makes every device abort its communicator before it synchronises; a round that exceeds the
+ * watchdog (1800 s; polar_debug_set "multi_timeout_s") has its communicators aborted from the calling thread. The call then
+ * returns POLAR_E_DEVICE and the next call rebuilds the communicators. */
+int polar_get_bler_quick_multi_ex(polar_code_t *h, int constellation, const int *devices, int n_dev, const double *axis, int n_e,
+                                  const uint8_t *L, int n_L, long max_runs, long max_err, uint64_t seed, long batch,
+                                  double *bler_out, double *ber_out, uint64_t *err_out, uint64_t *run_out, long *rounds_out,
+                                  int *used_rccl);
 
 /* test hook: number of ncclCommInitAll calls made by this library so far (the communicators and streams of a device
  * list are cached on the handle: a second polar_get_bler_quick_multi with the same list makes none). When a device's
@@ -208,12 +234,25 @@ int polar_set_tuning(polar_code_t *h, int waves_per_cu, int lds_log);
  * codeword in which one of them comes out below 1e-8 is decoded by the LLR-domain kernel whatever the mode, so automatic
  * mode is never worse there than mode 1 (DESIGN.md "Where bit-exactness ends"; tests/test_gpu_fuzz.py). With list sizes
  * below 3 mode 2 falls back to the LLR-domain kernel (the exp-domain kernels exist for groups of 4 lanes and more).
- * Environment overrides read at every decode (measurement and tests only): POLAR_MODE=<0|1|2> replaces the handle's mode;
+ * Environment overrides (measurement and tests only) are read ONCE, when a handle is created, and validated — no entry
+ * point calls getenv afterwards: POLAR_MODE=<0|1|2> replaces the handle's mode (any other value: creation fails);
  * POLAR_SC_NO_FOLD=1 makes the list-size-1 kernel decode a permuted, converted copy of the batch (its round-2 front pass)
- * instead of reading the caller's rows in place. Results do not depend on either. */
+ * instead of reading the caller's rows in place; POLAR_NO_TABLES=1, POLAR_NO_RCCL=1, POLAR_FORCE_RCCL=1. Results do not
+ * depend on any of them. */
 int polar_set_mode(polar_code_t *h, int mode);
-/* test hook: how many unfrozen leaves the handle classified as weak at creation (BEC(1/2) capacity below 1e-3; see above) */
+/* how many unfrozen leaves the handle classified as weak at creation (BEC(1/2) capacity below 1e-3; see above). Codes with
+ * weak leaves are accepted, but their decoded bits are the reference's only as far as the LLR-domain kernel reproduces
+ * glibc's rounding noise: polar_create_explicit() reports POLAR_W_WEAK_LEAVES (a positive, non-error status; the handle is
+ * valid) and this function the count. */
 int polar_debug_weak_leaves(const polar_code_t *h);
+/* test / measurement hooks. polar_debug_set: the knobs above after creation ("mode_override" -1|0|1|2, "sc_no_fold",
+ * "no_tables", "no_rccl", "force_rccl") and the ones that deliberately have NO environment form: "share_device" (one GPU
+ * may be listed several times in a device list), "fail_device" = d / "fail_collective" = d (worker d reports a failure in
+ * its second round before / after the barrier that precedes the counter reduction; -1 = off), "multi_timeout_s".
+ * polar_debug_get: "allocs" (hipMalloc calls of all handles' scratch so far), "comm_inits", "weak_leaves",
+ * "last_rounds", "last_round_max_per_device", "worker_threads_started" (of the handle's last get_bler_quick* calls). */
+int polar_debug_set(polar_code_t *h, const char *key, long value);
+long polar_debug_get(const polar_code_t *h, const char *key);
 
 #ifdef __cplusplus
 }

@@ -41,6 +41,13 @@ class PolarError(RuntimeError):
     pass
 
 
+class PolarWeakLeavesWarning(UserWarning):
+    """polar_create_explicit returned POLAR_W_WEAK_LEAVES (include/polar_amd.h)."""
+
+
+POLAR_W_WEAK_LEAVES = 1
+
+
 _lib = None
 
 
@@ -61,8 +68,10 @@ def lib():
 
 
 def _check(rc):
-    if rc != 0:
+    """Negative = error; positive = a non-error status (POLAR_W_WEAK_LEAVES), returned to the caller."""
+    if rc < 0:
         raise PolarError(f"polar_amd error {rc}: {lib().polar_last_error().decode()}")
+    return rc
 
 
 def _p(a, t):
@@ -100,6 +109,20 @@ class PolarCode:
         self.n, self.block_length, self.info_length, self.crc_size = n.value, N.value, K.value, crc.value
         self.N, self.K = self.block_length, self.info_length
 
+    @property
+    def weak_leaves(self):
+        """Unfrozen leaves the handle classified as weak at creation (polar_debug_weak_leaves)."""
+        return int(lib().polar_debug_weak_leaves(self._h))
+
+    def debug_set(self, key, value):
+        """Test / measurement hooks of include/polar_amd.h (polar_debug_set)."""
+        _check(lib().polar_debug_set(self._h, key.encode(), C.c_long(int(value))))
+
+    def debug_get(self, key):
+        f = lib().polar_debug_get
+        f.restype = C.c_long
+        return int(f(self._h, key.encode()))
+
     @classmethod
     def from_block_length(cls, block_length, info_length, design_epsilon, crc_size=0):
         n = int(round(np.log2(block_length)))
@@ -120,10 +143,14 @@ class PolarCode:
             if cm.shape != (crc_size, info_length):
                 raise PolarError("crc_matrix must be crc x K")
         h = C.c_void_p()
-        _check(lib().polar_create_explicit(C.c_int(num_layers), C.c_int(info_length), C.c_int(crc_size),
-                                           _p(frozen, _u8p), _p(order, _u16p),
-                                           _p(cm, _u8p) if cm is not None else None, C.byref(h)))
-        return cls(num_layers, info_length, float("nan"), crc_size, _handle=h)
+        status = _check(lib().polar_create_explicit(C.c_int(num_layers), C.c_int(info_length), C.c_int(crc_size),
+                                                    _p(frozen, _u8p), _p(order, _u16p),
+                                                    _p(cm, _u8p) if cm is not None else None, C.byref(h)))
+        code = cls(num_layers, info_length, float("nan"), crc_size, _handle=h)
+        if status == POLAR_W_WEAK_LEAVES:      # a valid handle; bit-exactness with the reference is limited (polar_amd.h)
+            import warnings
+            warnings.warn(f"polar_amd: {lib().polar_last_error().decode()}", PolarWeakLeavesWarning, stacklevel=2)
+        return code
 
     @classmethod
     def from_construction_file(cls, path, info_length, crc_size=0, crc_matrix=None):
@@ -362,30 +389,40 @@ class PolarCode:
                                         _p(enabled, _u8p), _p(err, _u64p), _p(bit_err, _u64p), _p(run, _u64p)))
 
     def get_bler_quick(self, ebno_vec, list_size_vec, max_runs=1000, max_err=100, seed=1, batch=None,
-                       return_ber=False, devices=None):
+                       return_ber=False, devices=None, constellation=None, return_counters=False):
         """PolarCode::get_bler_quick: returns bler[len(list_size_vec)][len(ebno_vec)] (PolarCode.cpp:658-785);
         with return_ber=True also PolarM's second output ber (PolarCode.m:781,848), same layout.
         batch=None: the library picks the rounds (see polar_amd.h). devices=[...]: shard the trials over these GPUs
-        of the node from this one process (polar_get_bler_quick_multi, RCCL all-reduce of the counters)."""
+        of the node from this one process (polar_get_bler_quick_multi_ex, RCCL all-reduce of the counters, one per round).
+        constellation="ask16-gray" (...): the ASK Gray + BICM front end with `ebno_vec` read as the SNR axis in dB
+        (PolarM/main_MC_CC_Comparison.m:44-119). return_counters=True: additionally a dict with the raw counters
+        err / run (uint64, same layout) and the number of rounds."""
         ebno = np.ascontiguousarray(ebno_vec, np.float64)
         Ls = np.ascontiguousarray(list_size_vec, np.uint8)
-        out = np.zeros((len(Ls), len(ebno)), np.float64)
-        ber = np.zeros((len(Ls), len(ebno)), np.float64)
+        shape = (len(Ls), len(ebno))
+        out = np.zeros(shape, np.float64)
+        ber = np.zeros(shape, np.float64)
+        err = np.zeros(shape, np.uint64)
+        run = np.zeros(shape, np.uint64)
         if batch is None:
             batch = 0
+        cid = 0 if constellation is None else _constellation_id(constellation)
         if devices is not None:
             devs = np.ascontiguousarray(devices, np.int32)
-            used = C.c_int(0)
-            _check(lib().polar_get_bler_quick_multi(self._h, devs.ctypes.data_as(C.POINTER(C.c_int)), C.c_int(len(devs)),
-                                                    _p(ebno, _dp), C.c_int(len(ebno)), _p(Ls, _u8p), C.c_int(len(Ls)),
-                                                    C.c_long(max_runs), C.c_long(max_err), C.c_uint64(seed), C.c_long(batch),
-                                                    _p(out, _dp), _p(ber, _dp), C.byref(used)))
-            self.last_used_rccl = bool(used.value)
+            dptr, nd = devs.ctypes.data_as(C.POINTER(C.c_int)), len(devs)
         else:
-            _check(lib().polar_get_bler_quick_ber(self._h, _p(ebno, _dp), C.c_int(len(ebno)), _p(Ls, _u8p), C.c_int(len(Ls)),
-                                                  C.c_long(max_runs), C.c_long(max_err), C.c_uint64(seed), C.c_long(batch),
-                                                  _p(out, _dp), _p(ber, _dp)))
-        return (out, ber) if return_ber else out
+            dptr, nd = None, 1
+        used, rounds = C.c_int(0), C.c_long(0)
+        _check(lib().polar_get_bler_quick_multi_ex(self._h, C.c_int(cid), dptr, C.c_int(nd),
+                                                   _p(ebno, _dp), C.c_int(len(ebno)), _p(Ls, _u8p), C.c_int(len(Ls)),
+                                                   C.c_long(max_runs), C.c_long(max_err), C.c_uint64(seed), C.c_long(batch),
+                                                   _p(out, _dp), _p(ber, _dp), _p(err, _u64p), _p(run, _u64p),
+                                                   C.byref(rounds), C.byref(used)))
+        self.last_used_rccl = bool(used.value)
+        res = (out, ber) if return_ber else (out,)
+        if return_counters:
+            res = res + ({"err": err, "run": run, "rounds": int(rounds.value)},)
+        return res[0] if len(res) == 1 else res
 
 
 # ---- Monte-Carlo code construction (PolarM/PolarCode.m:95-196) ---------------------------------

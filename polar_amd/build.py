@@ -25,6 +25,33 @@ SOURCES = [("polar_kernels.hip", ["POLAR_ED_TU=0"], "", []), ("polar_kernels.hip
            ("polar_kernels_sc.hip", [], "", []), ("polar_kernels_p1.hip", [], "", []), ("polar_channel.hip", [], "", []),
            ("polar_construct.hip", [], "", []), ("polar_host.cpp", [], "", [])]
 ARCH = os.environ.get("POLAR_ARCH", "gfx950")      # (A/B: e.g. gfx950:xnack-)
+_flags_ok = {}
+
+
+def _probe_flags(flags):
+    """The scheduler options of the list-of-32 translation unit are hidden LLVM options (-mllvm ...): a ROCm / LLVM that
+    does not know one of them stops with 'Unknown command line argument' and the whole build fails. Probed once per
+    process on an empty translation unit; unknown options are dropped (the kernel is then built with the default scheduler:
+    a few per cent slower, same results) and the fact is printed."""
+    key = tuple(flags)
+    if key not in _flags_ok:
+        import tempfile
+        ok = list(flags)
+        with tempfile.TemporaryDirectory() as d:
+            src = os.path.join(d, "probe.hip")
+            open(src, "w").write("#include <hip/hip_runtime.h>\n__global__ void probe_kernel() {}\n")
+            pairs = [flags[i:i + 2] for i in range(0, len(flags), 2)]          # ("-mllvm", "<option>")
+            ok = []
+            for pr in pairs:
+                r = subprocess.run([_hipcc(), "--offload-arch=" + ARCH, "-c", src, "-o", os.path.join(d, "probe.o")] + pr,
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+                if r.returncode == 0 or "Unknown command line argument" not in r.stderr:
+                    ok += pr              # (a probe that fails for any OTHER reason decides nothing: keep the option)
+                else:
+                    print("polar_amd.build: this compiler rejects %s (%s); building without it" %
+                          (" ".join(pr), (r.stderr.strip().splitlines() or ["?"])[-1][:120]), file=sys.stderr)
+        _flags_ok[key] = ok
+    return _flags_ok[key]
 
 
 def _hipcc():
@@ -117,12 +144,16 @@ def build(force=False, verbose=False, profile=False, bless=False):
             cmd.insert(1, "-DPOLAR_PROFILE")
         for d in defs + os.environ.get("POLAR_DEFS", "").split():
             cmd.insert(1, "-D" + d)
-        cmd[1:1] = xflags + os.environ.get("POLAR_HIPCC_FLAGS", "").split()    # (+ A/B experiments with compiler options)
+        cmd[1:1] = (_probe_flags(xflags) if xflags else []) + os.environ.get("POLAR_HIPCC_FLAGS", "").split()    # (+ A/B experiments with compiler options)
         fp = _fingerprint(cmd, [src] + _deps(obj, headers))
         stamp = obj + ".sha"
         have = open(stamp).read().strip() if os.path.exists(stamp) and os.path.exists(obj) else None
         if bless and os.path.exists(obj):
-            # adopt the existing object as built from the current sources (objects that predate the stamps)
+            # DEVELOPMENT ONLY: adopt the existing object as built from the current sources (objects that predate the
+            # stamps). Nothing checks that it really was: a stale object shipped this way no longer matches the sources.
+            if have != fp:
+                print("polar_amd.build --bless: WARNING: stamping %s as current WITHOUT compiling it; use only on a tree "
+                      "whose objects you know to be built from these sources" % os.path.basename(obj), file=sys.stderr)
             open(stamp, "w").write(fp)
             continue
         if force or have != fp:
@@ -177,4 +208,7 @@ def build_cli(force=False):
 
 
 if __name__ == "__main__":
+    if "--bless" in sys.argv and not os.environ.get("POLAR_DEV"):
+        raise SystemExit("polar_amd.build: --bless stamps existing objects as current without compiling them; it is a "
+                         "development aid and needs POLAR_DEV=1 in the environment")
     print(build(force="--force" in sys.argv, verbose=True, profile="--profile" in sys.argv, bless="--bless" in sys.argv))

@@ -84,15 +84,14 @@ public:
     std::vector<std::vector<double>> get_bler_quick(std::vector<double> ebno_vec, std::vector<uint8_t> list_size,
                                                     long max_runs = 1000, long max_err = 100, uint64_t seed = 1,
                                                     long batch = 0, std::vector<int> devices = {},
-                                                    std::vector<std::vector<double>> *ber = nullptr) {
+                                                    std::vector<std::vector<double>> *ber = nullptr, int constellation = 0) {
+        // constellation: 0 = BPSK / Eb/N0 axis (PolarCode.cpp:744-753); POLAR_CONST_ASK{4,8,16}_GRAY (polar_synth.h) = the ASK
+        // Gray + BICM sweep of PolarM/main_MC_CC_Comparison.m:44-119 with `ebno_vec` read as the SNR axis in dB
         std::vector<double> flat(ebno_vec.size() * list_size.size()), fber(flat.size());
-        if (devices.empty())
-            check(polar_get_bler_quick_ber(_h, ebno_vec.data(), (int)ebno_vec.size(), list_size.data(), (int)list_size.size(),
-                                           max_runs, max_err, seed, batch, flat.data(), fber.data()));   // batch 0: library rounds
-        else
-            check(polar_get_bler_quick_multi(_h, devices.data(), (int)devices.size(), ebno_vec.data(), (int)ebno_vec.size(),
-                                             list_size.data(), (int)list_size.size(), max_runs, max_err, seed, batch,
-                                             flat.data(), fber.data(), nullptr));
+        check(polar_get_bler_quick_multi_ex(_h, constellation, devices.empty() ? nullptr : devices.data(),
+                                            devices.empty() ? 1 : (int)devices.size(), ebno_vec.data(), (int)ebno_vec.size(),
+                                            list_size.data(), (int)list_size.size(), max_runs, max_err, seed, batch,   // batch 0: library rounds
+                                            flat.data(), fber.data(), nullptr, nullptr, nullptr, nullptr));
         std::vector<std::vector<double>> bler(list_size.size(), std::vector<double>(ebno_vec.size()));
         if (ber) ber->assign(list_size.size(), std::vector<double>(ebno_vec.size()));
         for (size_t l = 0; l < list_size.size(); ++l)
@@ -106,7 +105,7 @@ public:
 
 private:
     static void check(int rc) {
-        if (rc != POLAR_OK) throw std::runtime_error(std::string("polar_amd: ") + polar_last_error());
+        if (rc < 0) throw std::runtime_error(std::string("polar_amd: ") + polar_last_error());
     }
     static void need(bool ok, const char *msg) {
         if (!ok) throw std::out_of_range(msg);   // the reference throws out_of_range from .at()

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -20,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -49,6 +51,8 @@ int fail(int code, const char *fmt, ...) {
             return fail(POLAR_E_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+std::atomic<unsigned long> g_allocs{0};     // hipMalloc calls of the handles' scratch buffers so far (polar_debug_get "allocs")
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -57,6 +61,7 @@ struct DevBuf {
         if (n <= cap) return POLAR_OK;
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
+        ++g_allocs;
         hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
         if (e != hipSuccess) return fail(POLAR_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
         cap = n;
@@ -106,6 +111,19 @@ struct polar_code {
     DevBuf<uint32_t> d_list;
     DevBuf<unsigned int> d_count;
     int mode = 0;                    // 0 auto, 1 LLR-domain kernel only, 2 exp-domain kernel + fallback pass
+    // Measurement / test knobs. The environment is read ONCE, when the handle is created (read_env_knobs): a decode never
+    // calls getenv. The fault-injection and device-sharing hooks have no environment form at all: polar_debug_set() only.
+    struct Knobs {
+        int mode_override = -1;      // POLAR_MODE=<0|1|2>: replaces `mode`
+        bool sc_no_fold = false;     // POLAR_SC_NO_FOLD: list size 1 decodes a permuted, converted copy (front pass)
+        bool no_tables = false;      // POLAR_NO_TABLES: list of 17..32 without the layer-1/2 value tables
+        bool no_rccl = false;        // POLAR_NO_RCCL: multi-device counters summed on the host
+        bool force_rccl = false;     // POLAR_FORCE_RCCL: RCCL even with one device
+        bool share_device = false;   // (test hook) one GPU may be listed several times: separate contexts, host-side sum
+        int fail_device = -1;        // (test hook) this worker reports a failure in its second round, before the collective
+        int fail_collective = -1;    // (test hook) this worker's collective enqueue "fails" in its second round (after the barrier)
+        long multi_timeout_s = 1800; // watchdog of a multi-device round: communicators are aborted when a round takes longer
+    } knobs;
     // Monte-Carlo engine (device side): alive lists (double-buffered), their lengths, per-round counters
     DevBuf<uint64_t> d_alive[2];
     DevBuf<unsigned int> d_nalive;           // [2]
@@ -115,6 +133,8 @@ struct polar_code {
     // streams + RCCL communicators of the last multi-device call, kept for the next one with the same device list
     // (an 8-rank ncclCommInitAll costs about as long as a short sweep runs)
     struct MultiCtx *multi = nullptr;
+    // statistics of the last get_bler_quick* call (polar_debug_get)
+    long last_rounds = 0, last_round_max_per_device = 0, worker_threads_started = 0;
     // tuning
     int waves_per_cu = 0, lds_log = 0, pipe = -1;
     bool prefix_on = true;
@@ -306,6 +326,22 @@ int ensure_device(polar_code *h, DevGuard &dg) {
 
 int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+// The measurement knobs of the environment, read ONCE per handle (at creation) and validated; nothing below ever calls
+// getenv again (it races with setenv in multi-threaded hosts, and a deployed library must not change its kernel path
+// because a variable appeared). polar_debug_set() changes them afterwards (tests, A/B tools).
+int read_env_knobs(polar_code *h) {
+    auto on = [](const char *name) { const char *e = getenv(name); return e && *e && strcmp(e, "0") != 0; };
+    if (const char *e = getenv("POLAR_MODE")) {
+        if (!(e[0] >= '0' && e[0] <= '2' && e[1] == 0)) return fail(POLAR_E_ARG, "POLAR_MODE=%s: must be 0, 1 or 2", e);
+        h->knobs.mode_override = e[0] - '0';
+    }
+    h->knobs.sc_no_fold = on("POLAR_SC_NO_FOLD");
+    h->knobs.no_tables = on("POLAR_NO_TABLES");
+    h->knobs.no_rccl = on("POLAR_NO_RCCL");
+    h->knobs.force_rccl = on("POLAR_FORCE_RCCL");
+    return POLAR_OK;
+}
+
 void multi_release(polar_code *h, bool abort_comms);     // (defined next to bler_impl)
 
 }  // namespace
@@ -349,6 +385,7 @@ int polar_create(int n, int K, double eps, int crc, polar_code_t **out) {
     for (int b = 0; b < crc; ++b)
         for (int j = 0; j < K; ++j) h->crcm[(size_t)b * K + j] = (uint8_t)(rand() % 2);
     int rc = derive_tables(h);
+    if (!rc) rc = read_env_knobs(h);
     if (rc) { delete h; return rc; }
     (void)hipGetDevice(&h->device);          // bound to the current device (stays -1 when none is visible yet)
     *out = h;
@@ -370,9 +407,12 @@ int polar_create_explicit(int n, int K, int crc, const uint8_t *frozen, const ui
     h->crcm.assign((size_t)crc * K, 0);
     if (crc) memcpy(h->crcm.data(), crc_matrix, (size_t)crc * K);
     int rc = derive_tables(h);
+    if (!rc) rc = read_env_knobs(h);
     if (rc) { delete h; return rc; }
     (void)hipGetDevice(&h->device);
     *out = h;
+    // a valid handle, and a status the caller can see: unfrozen leaves in the worst synthetic channels (derive_tables)
+    if (h->weak_leaves) { g_err = "explicit table leaves " + std::to_string(h->weak_leaves) + " unfrozen leaves in channels of BEC(1/2) capacity below 1e-3"; return POLAR_W_WEAK_LEAVES; }
     return POLAR_OK;
 }
 
@@ -431,6 +471,39 @@ static void drop_clones(polar_code_t *h) {
 
 // test hook: number of unfrozen leaves derive_tables() marked as weak (see there)
 int polar_debug_weak_leaves(const polar_code_t *h) { return h ? h->weak_leaves : -1; }
+
+// test / measurement hooks (include/polar_amd.h): the knobs the environment sets at creation, and the ones that have no
+// environment form
+int polar_debug_set(polar_code_t *h, const char *key, long value) {
+    if (!h || !key) return fail(POLAR_E_ARG, "NULL argument");
+    polar_code::Knobs &k = h->knobs;
+    const std::string s(key);
+    if (s == "mode_override") { if (value < -1 || value > 2) return fail(POLAR_E_ARG, "mode_override must be -1 (none), 0, 1 or 2"); k.mode_override = (int)value; }
+    else if (s == "sc_no_fold") k.sc_no_fold = value != 0;
+    else if (s == "no_tables") k.no_tables = value != 0;
+    else if (s == "no_rccl") k.no_rccl = value != 0;
+    else if (s == "force_rccl") k.force_rccl = value != 0;
+    else if (s == "share_device") k.share_device = value != 0;
+    else if (s == "fail_device") k.fail_device = (int)value;
+    else if (s == "fail_collective") k.fail_collective = (int)value;
+    else if (s == "multi_timeout_s") { if (value < 0) return fail(POLAR_E_ARG, "multi_timeout_s must be >= 0 (0 = no watchdog)"); k.multi_timeout_s = value; }
+    else return fail(POLAR_E_ARG, "polar_debug_set: unknown key '%s'", key);
+    drop_clones(h);          // (the per-device contexts carry a copy of the knobs)
+    return POLAR_OK;
+}
+long polar_debug_get(const polar_code_t *h, const char *key) {
+    if (!key) return -1;
+    const std::string s(key);
+    if (s == "allocs") return (long)g_allocs.load();
+    if (s == "comm_inits") return (long)polar_debug_comm_inits();
+    if (!h) return -1;
+    if (s == "weak_leaves") return h->weak_leaves;
+    if (s == "mode_override") return h->knobs.mode_override;
+    if (s == "last_rounds") return h->last_rounds;
+    if (s == "last_round_max_per_device") return h->last_round_max_per_device;
+    if (s == "worker_threads_started") return h->worker_threads_started;
+    return -1;
+}
 
 int polar_set_crc_matrix(polar_code_t *h, const uint8_t *m) {
     if (!h || (!m && h->crc)) return fail(POLAR_E_ARG, "NULL argument");
@@ -554,8 +627,7 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
     // list sizes where the f-node dominates; codewords it flags (decisions within 1e-10 of the |x| < 40
     // test, degenerate inputs) are decoded again by the LLR-domain kernel in a fallback pass over a
     // device-side work list: no host synchronisation, normally zero entries.
-    int mode = h->mode;
-    if (const char *e = getenv("POLAR_MODE")) mode = atoi(e);
+    const int mode = h->knobs.mode_override >= 0 ? h->knobs.mode_override : h->mode;
     if (L == 1 && mode != 1 && !d_pm) {          // (a requested path metric needs the general kernel: this one has none)
         // ---- list size 1: pruned successive cancellation, eight lanes per codeword (polar_kernels_sc.hip); flagged
         // codewords (degenerate inputs, |x| < 40 decisions too close to call) go through the general kernel below
@@ -563,7 +635,9 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
         // (measured and dropped: as many waves as make the rounds of eight-codeword groups whole — 4 096 instead of 5 120 for
         // 65 536 codewords — is 2.5 % SLOWER: the kernel wants the latency hiding of 20 waves per CU more than a full last round)
         const int sgrid = (int)std::min<long>(groups8, (long)h->num_cu * polar_sc8_waves_per_cu(h->N));
-        const bool fold = h->sc_fold && !getenv("POLAR_SC_NO_FOLD");      // (the variable: A/B measurements and the parity tests of both paths)
+        // (the in-place reads are 16-byte vector loads: a caller's pointer that is not 16-byte aligned takes the front pass; the knob:
+        // A/B measurements and the parity tests of both paths)
+        const bool fold = h->sc_fold && !h->knobs.sc_no_fold && ((uintptr_t)d_llr & 15u) == 0;
         if (!fold && (rc = h->d_ech.ensure((size_t)B * h->N))) return rc;
         if ((rc = h->d_flags.ensure((size_t)B))) return rc;
         if ((rc = h->d_list.ensure((size_t)B))) return rc;
@@ -614,7 +688,7 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
     HIP_TRY(polar_launch_ed_front(d_llr, llr_f32, h->d_ech.p, h->d_flags.p, h->d_tabs.p, h->N, B, n_dev, st));
     PolarDecodeParams pe = p;
     pe.llr = h->d_ech.p; pe.llr_f32 = 0; pe.flags = h->d_flags.p;
-    if (gs == 32 && !pipe && h->N >= 1024 && p.prefix_q > 0 && !getenv("POLAR_NO_TABLES")) {
+    if (gs == 32 && !pipe && h->N >= 1024 && p.prefix_q > 0 && !h->knobs.no_tables) {
         // table mode: layers 1 and 2 as per-codeword value tables (polar_kernels.hip)
         if ((rc = h->d_tab_scr.ensure((size_t)grid * G * 3 * h->N + 64))) return rc;
         if ((rc = h->d_var_scr.ensure((size_t)grid * (h->N / 32) * 64 + 64))) return rc;
@@ -793,22 +867,29 @@ int polar_synth_llr_dev(polar_code_t *h, uint64_t seed, uint64_t trial0, long B,
     return POLAR_OK;
 }
 
-// Pre-size every device scratch buffer a decode of (B codewords, list size L) needs, by running one on generated inputs:
-// afterwards polar_decode_scl_llr_batch_dev* calls of at most that size allocate nothing (no hipFree / hipMalloc, i.e. no
-// implicit device synchronisation, inside the nominally asynchronous calls).
+// Pre-size every device scratch buffer decodes of up to B codewords at list sizes 1 .. L need, by running one decode per
+// kernel family on generated inputs (list size 1: the pruned SC kernel and its flag words; 2: the LLR-domain kernel's 2-lane
+// groups; every power-of-two lane group up to pow2ceil(L), with and without the path-metric output): afterwards
+// polar_decode_scl_llr_batch_dev* calls within (B, L) allocate nothing (no hipFree / hipMalloc, i.e. no implicit device
+// synchronisation, inside the nominally asynchronous calls; polar_debug_get "allocs" counts them).
 int polar_reserve(polar_code_t *h, long B, int L) {
     if (!h) return fail(POLAR_E_ARG, "NULL handle");
+    if (L < 1 || L > POLAR_MAX_LIST) return fail(POLAR_E_ARG, "list size %d out of range [1, %d]", L, POLAR_MAX_LIST);
     if (B <= 0) return B == 0 ? POLAR_OK : fail(POLAR_E_ARG, "negative batch");
     DevGuard dg_;
     int rc = ensure_device(h, dg_);
     if (rc) return rc;
-    DevBuf<double> llr;
+    DevBuf<double> llr, pm;
     DevBuf<uint8_t> out;
-    if ((rc = llr.ensure((size_t)B * h->N)) || (rc = out.ensure((size_t)B * h->K))) { llr.release(); out.release(); return rc; }
+    if ((rc = llr.ensure((size_t)B * h->N)) || (rc = out.ensure((size_t)B * h->K)) || (rc = pm.ensure((size_t)B))) { llr.release(); out.release(); pm.release(); return rc; }
     rc = polar_synth_llr_dev(h, 1, 0, B, polar_snr_sqrt_linear(h, 2.0), llr.p, nullptr, nullptr);
-    if (!rc) rc = polar_decode_scl_llr_batch_dev(h, llr.p, B, L, out.p, nullptr, nullptr);
+    const int top = std::min(pow2ceil(L), POLAR_MAX_LIST);
+    for (int l = 1; l <= top && !rc; l <<= 1) {
+        rc = polar_decode_scl_llr_batch_dev(h, llr.p, B, l, out.p, nullptr, nullptr);
+        if (!rc && l == 1) rc = polar_decode_scl_llr_batch_dev(h, llr.p, B, l, out.p, pm.p, nullptr);   // (a requested metric: the general kernel)
+    }
     hipError_t e = hipDeviceSynchronize();
-    llr.release(); out.release();
+    llr.release(); out.release(); pm.release();
     if (!rc && e != hipSuccess) return fail(POLAR_E_DEVICE, "polar_reserve: %s", hipGetErrorString(e));
     return rc;
 }
@@ -1047,12 +1128,77 @@ struct HostBarrier {
 
 }  // namespace
 
-// streams and communicators of a device list, owned by the handle (polar_code::multi)
+// streams, communicators and worker threads of a device list, owned by the handle (polar_code::multi)
 struct MultiCtx {
     std::vector<int> devs;               // as listed by the caller
     std::vector<hipStream_t> streams;
     std::vector<void *> comms;           // empty without RCCL
     bool rccl = false;
+    // Persistent worker pool: one thread per device, created with the context and parked between rounds (round 3 created
+    // and joined n_dev threads every round). run_all() hands every worker the same job and waits for all of them; with a
+    // watchdog: when a round takes longer than `timeout_s` the communicators are aborted from the waiting thread, which
+    // releases workers blocked in a collective that a peer never entered or never finished.
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    std::function<void(int)> job;
+    unsigned gen = 0;
+    int pending = 0;
+    bool quit = false, timed_out = false;
+    std::unique_ptr<HostBarrier> bar;
+
+    void start_workers(int n) {
+        bar.reset(new HostBarrier(n));
+        if (n <= 1) return;                          // a single device runs on the calling thread
+        for (int d = 0; d < n; ++d)
+            threads.emplace_back([this, d] {
+                unsigned seen = 0;
+                for (;;) {
+                    std::function<void(int)> f;
+                    {
+                        std::unique_lock<std::mutex> lk(m);
+                        cv_job.wait(lk, [&] { return quit || gen != seen; });
+                        if (quit) return;
+                        seen = gen;
+                        f = job;
+                    }
+                    f(d);
+                    {
+                        std::lock_guard<std::mutex> lk(m);
+                        if (--pending == 0) cv_done.notify_all();
+                    }
+                }
+            });
+    }
+    void abort_comms() {                             // (any thread; ncclCommAbort exists to be called on a stuck communicator)
+        for (size_t d = 0; d < comms.size(); ++d)
+            if (comms[d] && g_rccl.CommAbort) { (void)g_rccl.CommAbort(comms[d]); comms[d] = nullptr; }
+    }
+    void run_all(const std::function<void(int)> &f, long timeout_s) {
+        const int n = (int)devs.size();
+        if (threads.empty()) { for (int d = 0; d < n; ++d) f(d); return; }
+        std::unique_lock<std::mutex> lk(m);
+        job = f; pending = n; ++gen;
+        cv_job.notify_all();
+        if (timeout_s > 0) {
+            if (!cv_done.wait_for(lk, std::chrono::seconds(timeout_s), [&] { return pending == 0; })) {
+                timed_out = true;
+                lk.unlock();
+                abort_comms();                       // frees workers blocked in hipStreamSynchronize behind a dead collective
+                lk.lock();
+                cv_done.wait(lk, [&] { return pending == 0; });
+            }
+        } else cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    void stop_workers() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            quit = true;
+        }
+        cv_job.notify_all();
+        for (auto &t : threads) t.join();
+        threads.clear();
+    }
 };
 
 namespace {
@@ -1061,6 +1207,7 @@ void multi_release(polar_code *h, bool abort_comms) {
     MultiCtx *m = h->multi;
     if (!m) return;
     h->multi = nullptr;
+    m->stop_workers();
     int prev = -1;
     (void)hipGetDevice(&prev);
     for (size_t d = 0; d < m->comms.size(); ++d)
@@ -1076,7 +1223,7 @@ void multi_release(polar_code *h, bool abort_comms) {
 }
 // the handle's tables on another device (owned by `h`, reused by later calls)
 polar_code *clone_on_device(polar_code *h, int dev, bool fresh = false) {
-    // fresh: a context of its own even when one exists for this device (test hook POLAR_TEST_SHARE_DEVICE)
+    // fresh: a context of its own even when one exists for this device (test hook share_device)
     if (!fresh) {
         if (dev == h->device) return h;
         for (polar_code *c : h->clones) if (c->device == dev) return c;
@@ -1088,22 +1235,33 @@ polar_code *clone_on_device(polar_code *h, int dev, bool fresh = false) {
     c->sc_ops = h->sc_ops; c->sc_fold = h->sc_fold; c->weak_leaves = h->weak_leaves;
     c->device = dev;
     c->waves_per_cu = h->waves_per_cu; c->lds_log = h->lds_log; c->pipe = h->pipe; c->prefix_on = h->prefix_on; c->mode = h->mode;
+    c->knobs = h->knobs;
     h->clones.push_back(c);
     return c;
 }
 
-// round sizes: `batch` fixed, or (batch == 0) geometric — the first round is max(256, 2 max_err) trials, every later
-// one as many as all rounds before it together (at most 262144): the early stop `num_err > max_err` (:725) keeps its
-// meaning (a point overshoots its stopping time by less than 2x) and long sweeps still reach full-size launches
-long next_round(long batch, long max_err, long done, long max_runs) {
-    long T = batch > 0 ? batch : (done == 0 ? std::max<long>(256, 2 * max_err) : std::min<long>(done, 262144));
+// Round sizes (trials of one round over ALL devices): `batch` fixed, or (batch == 0) geometric — the first round is
+// max(256, 2 max_err) trials (rounded up to a multiple of the device count), every later one as many as all rounds before
+// it together, at most 262144 PER DEVICE: the early stop `num_err > max_err` (:725) keeps its meaning (a point overshoots
+// its stopping time by less than 2x) and long sweeps reach full-size launches on every device. (Round 3 capped the round
+// over all devices: at 8 GPUs each got 32768 trials per round — four resident rounds of the list-of-32 kernel, less than
+// one of the list-size-1 kernel.)
+long next_round(long batch, long max_err, long done, long max_runs, int n_dev) {
+    long T;
+    if (batch > 0) T = batch;
+    else if (done == 0) { T = std::max<long>(256, 2 * max_err); T = ((T + n_dev - 1) / n_dev) * n_dev; }
+    else T = std::min<long>(done, 262144L * n_dev);
     return std::min(T, max_runs - done);
 }
 
-int bler_impl(polar_code_t *h, const int *devices, int n_dev, const double *ebno, int n_e, const uint8_t *Ls, int n_L,
-              long max_runs, long max_err, uint64_t seed, long batch, double *bler_out, double *ber_out, int *used_rccl) {
+int bler_impl(polar_code_t *h, int constellation, const int *devices, int n_dev, const double *ebno, int n_e, const uint8_t *Ls, int n_L,
+              long max_runs, long max_err, uint64_t seed, long batch, double *bler_out, double *ber_out,
+              uint64_t *err_out, uint64_t *run_out, int *used_rccl) {
     if (!h || !ebno || !Ls || !bler_out) return fail(POLAR_E_ARG, "NULL argument");
     if (n_e <= 0 || n_L <= 0 || max_runs <= 0 || batch < 0 || n_dev < 1) return fail(POLAR_E_ARG, "bad sizes");
+    if (constellation == POLAR_CONST_BPSK) constellation = 0;
+    if (constellation != 0 && (constellation < POLAR_CONST_ASK4_GRAY || constellation > POLAR_CONST_ASK16_GRAY))
+        return fail(POLAR_E_ARG, "unknown constellation %d", constellation);
     for (int i = 0; i < n_L; ++i)
         if (Ls[i] < 1 || Ls[i] > POLAR_MAX_LIST) return fail(POLAR_E_ARG, "list size %d out of range", (int)Ls[i]);
     const int P = n_e * n_L;
@@ -1111,8 +1269,8 @@ int bler_impl(polar_code_t *h, const int *devices, int n_dev, const double *ebno
     std::vector<uint8_t> en(P, 1);
     DevGuard dg_;
     (void)hipGetDevice(&dg_.prev);
-    // one context (clone of the tables + scratch) per device; streams and communicators live on the handle and are
-    // reused by the next call with the same device list
+    // one context (clone of the tables + scratch) per device; streams, communicators and worker threads live on the
+    // handle and are reused by the next call with the same device list
     std::vector<polar_code *> ctx(n_dev);
     std::vector<int> devs(n_dev);
     int ndev_visible = 0;
@@ -1125,14 +1283,14 @@ int bler_impl(polar_code_t *h, const int *devices, int n_dev, const double *ebno
         devs[d] = dev;
         for (int e = 0; e < d; ++e)
             if (devs[e] == dev) {
-                // (test hook: POLAR_TEST_SHARE_DEVICE lets one GPU stand in for several, so that the per-device contexts,
-                // worker threads, strided trial partition and counter sum are exercised on a single-GPU box; RCCL cannot
-                // have two ranks on one device, the counters are then summed on the host)
-                if (!getenv("POLAR_TEST_SHARE_DEVICE")) return fail(POLAR_E_ARG, "device %d listed twice", dev);
+                // (test hook share_device — polar_debug_set, no environment form — lets one GPU stand in for several, so
+                // that the per-device contexts, worker threads, strided trial partition and counter sum are exercised on a
+                // single-GPU box; RCCL cannot have two ranks on one device, the counters are then summed on the host)
+                if (!h->knobs.share_device) return fail(POLAR_E_ARG, "device %d listed twice", dev);
                 dup = true;
             }
     }
-    const bool want_rccl = (n_dev > 1 || getenv("POLAR_FORCE_RCCL")) && !getenv("POLAR_NO_RCCL") && !dup;
+    const bool want_rccl = (n_dev > 1 || h->knobs.force_rccl) && !h->knobs.no_rccl && !dup;
     if (h->multi && (h->multi->devs != devs || (want_rccl && !h->multi->rccl && g_rccl.load()))) multi_release(h, false);
     for (int d = 0; d < n_dev; ++d) {
         bool again = false;
@@ -1170,6 +1328,8 @@ int bler_impl(polar_code_t *h, const int *devices, int n_dev, const double *ebno
             m->rccl = (g_rccl.CommInitAll(m->comms.data(), n_dev, devs.data()) == 0);
             if (!m->rccl) m->comms.clear();
         }
+        m->start_workers(n_dev);
+        h->worker_threads_started += (long)m->threads.size();
     }
     MultiCtx *mc = h->multi;
     const std::vector<hipStream_t> &streams = mc->streams;
@@ -1177,58 +1337,67 @@ int bler_impl(polar_code_t *h, const int *devices, int n_dev, const double *ebno
     if (used_rccl) *used_rccl = rccl ? 1 : 0;
     int rc_all = POLAR_OK;
     std::string err_msg;
-    // test hook: POLAR_TEST_FAIL_DEVICE=<d> makes worker d report a failure in its second round (the abort path below
-    // cannot be reached with healthy hardware)
-    const int fail_dev = getenv("POLAR_TEST_FAIL_DEVICE") ? atoi(getenv("POLAR_TEST_FAIL_DEVICE")) : -1;
+    const int fail_dev = h->knobs.fail_device, fail_coll = h->knobs.fail_collective;     // (test hooks)
     int round_no = 0;
+    h->last_rounds = 0; h->last_round_max_per_device = 0;
+    std::vector<int> rcs(n_dev);
+    std::vector<std::string> msgs(n_dev);
+    std::vector<long> Td(n_dev);
+    std::vector<std::vector<unsigned long long>> host_ctr(n_dev, std::vector<unsigned long long>((size_t)2 * P, 0));
     for (long done = 0; done < max_runs; ++round_no) {
         bool any = false;
         for (int i = 0; i < P; ++i) { en[i] = (err[i] <= (uint64_t)max_err); any |= en[i]; }   // :725
         if (!any) break;
-        const long T = next_round(batch, max_err, done, max_runs);       // trials of this round, all devices together
+        const long T = next_round(batch, max_err, done, max_runs, n_dev);      // trials of this round, all devices together
         // device d simulates the trials done + d, done + d + n_dev, ... (counter-based inputs: the union does not
         // depend on n_dev)
-        std::vector<int> rcs(n_dev, POLAR_OK);
-        std::vector<std::string> msgs(n_dev);
-        std::vector<long> Td(n_dev);
-        std::vector<std::vector<unsigned long long>> host_ctr(n_dev, std::vector<unsigned long long>((size_t)2 * P, 0));
-        HostBarrier bar(n_dev);
-        std::atomic<int> n_failed{0};
+        std::fill(rcs.begin(), rcs.end(), POLAR_OK);
+        for (auto &s_ : msgs) s_.clear();
+        std::atomic<int> n_failed{0}, n_failed_coll{0};
+        HostBarrier &bar = *mc->bar;
         auto worker = [&](int d) {
             polar_code *c = ctx[d];
             Td[d] = (T - d + n_dev - 1) / n_dev;
             int rc = POLAR_OK;
             if (hipSetDevice(c->device) != hipSuccess) { rc = POLAR_E_DEVICE; msgs[d] = "hipSetDevice failed"; }
-            else if (d == fail_dev && round_no == 1) { rc = POLAR_E_DEVICE; msgs[d] = "injected failure (POLAR_TEST_FAIL_DEVICE)"; }
+            else if (d == fail_dev && round_no == 1) { rc = POLAR_E_DEVICE; msgs[d] = "injected failure (fail_device)"; }
             else if (Td[d] > 0)
-                rc = mc_round_launch(c, 0, seed, (uint64_t)(done + d), Td[d], n_dev, ebno, n_e, Ls, n_L, en.data(), streams[d]);
+                rc = mc_round_launch(c, constellation, seed, (uint64_t)(done + d), Td[d], n_dev, ebno, n_e, Ls, n_L, en.data(), streams[d]);
             else
                 rc = (c->d_mc_ctr.ensure((size_t)2 * P) || hipMemsetAsync(c->d_mc_ctr.p, 0, (size_t)2 * P * 8, streams[d]) != hipSuccess) ? POLAR_E_DEVICE : POLAR_OK;
             if (rc && msgs[d].empty()) msgs[d] = polar_last_error();
-            // every worker learns whether ALL of them got this far: a rank that skipped the collective on its own would
-            // leave the others blocked in it for good
+            // (1) every worker learns whether ALL of them got this far: either every one enters the collective or none does
+            // (a lone rank skipping it would leave the others blocked in it for good)
             if (rc) ++n_failed;
             if (n_dev > 1) bar.wait();
             const bool round_ok = (n_failed.load() == 0);
-            if (round_ok && rccl) {
+            bool coll_failed = false;
+            if (round_ok) {
                 // sum of the round's counters over the devices (xGMI), in place on every device
-                if (g_rccl.AllReduce(c->d_mc_ctr.p, c->d_mc_ctr.p, (size_t)2 * P, kNcclUint64, kNcclSum, mc->comms[d], streams[d]) != 0) {
-                    rc = POLAR_E_DEVICE; msgs[d] = "ncclAllReduce failed";
+                if (d == fail_coll && round_no == 1) coll_failed = true;       // (test hook: the enqueue "fails" on this rank only)
+                else if (rccl && g_rccl.AllReduce(c->d_mc_ctr.p, c->d_mc_ctr.p, (size_t)2 * P, kNcclUint64, kNcclSum, mc->comms[d], streams[d]) != 0)
+                    coll_failed = true;
+                if (coll_failed) { rc = POLAR_E_DEVICE; msgs[d] = (d == fail_coll && round_no == 1) ? "injected failure (fail_collective)" : "ncclAllReduce failed"; ++n_failed_coll; }
+                // (2) a rank whose enqueue failed AFTER the first barrier would leave its peers blocked in
+                // hipStreamSynchronize behind a collective that never completes: everybody meets again, and when any
+                // enqueue failed every rank aborts its own communicator BEFORE it synchronises
+                if (n_dev > 1) bar.wait();
+                if (n_failed_coll.load() != 0) {
+                    if (rccl && mc->comms[d] && g_rccl.CommAbort) { (void)g_rccl.CommAbort(mc->comms[d]); mc->comms[d] = nullptr; }
+                    if (!rc) { rc = POLAR_E_DEVICE; msgs[d] = "round aborted: the counter reduction failed on another device"; }
+                } else if (!rccl || d == 0) {
+                    if (hipMemcpyAsync(host_ctr[d].data(), c->d_mc_ctr.p, (size_t)2 * P * 8, hipMemcpyDeviceToHost, streams[d]) != hipSuccess) { rc = POLAR_E_DEVICE; msgs[d] = "counter copy failed"; }
                 }
-            }
-            if (round_ok && !rc && (!rccl || d == 0)) {
-                if (hipMemcpyAsync(host_ctr[d].data(), c->d_mc_ctr.p, (size_t)2 * P * 8, hipMemcpyDeviceToHost, streams[d]) != hipSuccess) { rc = POLAR_E_DEVICE; msgs[d] = "counter copy failed"; }
-            }
+            } else if (!rc) { rc = POLAR_E_DEVICE; msgs[d] = "round aborted: another device failed"; }
             if (hipStreamSynchronize(streams[d]) != hipSuccess && !rc) { rc = POLAR_E_DEVICE; msgs[d] = "stream synchronize failed"; }
             rcs[d] = rc;
         };
-        if (n_dev == 1) worker(0);
-        else {
-            std::vector<std::thread> th;
-            for (int d = 0; d < n_dev; ++d) th.emplace_back(worker, d);
-            for (auto &t : th) t.join();
-        }
-        for (int d = 0; d < n_dev; ++d) if (rcs[d]) { rc_all = rcs[d]; err_msg = "device " + std::to_string(devs[d]) + ": " + msgs[d]; }
+        mc->run_all(worker, h->knobs.multi_timeout_s);
+        if (mc->timed_out) { rc_all = POLAR_E_DEVICE; err_msg = "a multi-device round exceeded the watchdog (" + std::to_string(h->knobs.multi_timeout_s) + " s): communicators aborted"; }
+        // report the device that failed first-hand, not a peer that was merely told to stop
+        for (int pass = 0; pass < 2 && !rc_all; ++pass)
+            for (int d = 0; d < n_dev; ++d)
+                if (rcs[d] && (pass == 1 || msgs[d].compare(0, 13, "round aborted") != 0)) { rc_all = rcs[d]; err_msg = "device " + std::to_string(devs[d]) + ": " + msgs[d]; break; }
         if (rc_all) break;
         for (int i = 0; i < P; ++i) {
             if (!en[i]) continue;
@@ -1236,6 +1405,8 @@ int bler_impl(polar_code_t *h, const int *devices, int n_dev, const double *ebno
             run[i] += (uint64_t)T;
         }
         done += T;
+        ++h->last_rounds;
+        h->last_round_max_per_device = std::max(h->last_round_max_per_device, Td[0]);
     }
     // a failed round leaves the communicators in an unknown state: abort and rebuild them next time
     if (rc_all) multi_release(h, true);
@@ -1243,6 +1414,8 @@ int bler_impl(polar_code_t *h, const int *devices, int n_dev, const double *ebno
     for (int i = 0; i < P; ++i) {
         bler_out[i] = run[i] ? (double)err[i] / (double)run[i] : 0.0;                 // :777-781
         if (ber_out) ber_out[i] = run[i] ? (double)bit[i] / (double)run[i] : 0.0;     // PolarM/PolarCode.m:848 (per run, as the reference)
+        if (err_out) err_out[i] = err[i];
+        if (run_out) run_out[i] = run[i];
     }
     return POLAR_OK;
 }
@@ -1256,20 +1429,34 @@ int polar_get_bler_quick(polar_code_t *h, const double *ebno, int n_e, const uin
     if (!h) return fail(POLAR_E_ARG, "NULL argument");
     int dev = h->device;
     if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return fail(POLAR_E_DEVICE, "no HIP device available; this library has no CPU decode path");
-    return bler_impl(h, &dev, 1, ebno, n_e, Ls, n_L, max_runs, max_err, seed, batch, bler_out, nullptr, nullptr);
+    return bler_impl(h, 0, &dev, 1, ebno, n_e, Ls, n_L, max_runs, max_err, seed, batch, bler_out, nullptr, nullptr, nullptr, nullptr);
 }
 int polar_get_bler_quick_ber(polar_code_t *h, const double *ebno, int n_e, const uint8_t *Ls, int n_L,
                              long max_runs, long max_err, uint64_t seed, long batch, double *bler_out, double *ber_out) {
     if (!h) return fail(POLAR_E_ARG, "NULL argument");
     int dev = h->device;
     if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return fail(POLAR_E_DEVICE, "no HIP device available; this library has no CPU decode path");
-    return bler_impl(h, &dev, 1, ebno, n_e, Ls, n_L, max_runs, max_err, seed, batch, bler_out, ber_out, nullptr);
+    return bler_impl(h, 0, &dev, 1, ebno, n_e, Ls, n_L, max_runs, max_err, seed, batch, bler_out, ber_out, nullptr, nullptr, nullptr);
 }
 int polar_debug_comm_inits(void) { return g_comm_inits.load(); }
 int polar_get_bler_quick_multi(polar_code_t *h, const int *devices, int n_dev, const double *ebno, int n_e,
                                const uint8_t *Ls, int n_L, long max_runs, long max_err, uint64_t seed, long batch,
                                double *bler_out, double *ber_out, int *used_rccl) {
-    return bler_impl(h, devices, n_dev, ebno, n_e, Ls, n_L, max_runs, max_err, seed, batch, bler_out, ber_out, used_rccl);
+    return bler_impl(h, 0, devices, n_dev, ebno, n_e, Ls, n_L, max_runs, max_err, seed, batch, bler_out, ber_out, nullptr, nullptr, used_rccl);
+}
+int polar_get_bler_quick_multi_ex(polar_code_t *h, int constellation, const int *devices, int n_dev, const double *axis, int n_e,
+                                  const uint8_t *Ls, int n_L, long max_runs, long max_err, uint64_t seed, long batch,
+                                  double *bler_out, double *ber_out, uint64_t *err_out, uint64_t *run_out, long *rounds_out,
+                                  int *used_rccl) {
+    if (!h) return fail(POLAR_E_ARG, "NULL argument");
+    int dev0 = h->device;
+    if (!devices && n_dev == 1 && dev0 < 0 && hipGetDevice(&dev0) != hipSuccess)
+        return fail(POLAR_E_DEVICE, "no HIP device available; this library has no CPU decode path");
+    // (devices == NULL with one device: the handle's own, like polar_get_bler_quick)
+    const int rc = bler_impl(h, constellation, (!devices && n_dev == 1) ? &dev0 : devices, n_dev, axis, n_e, Ls, n_L, max_runs, max_err, seed, batch,
+                             bler_out, ber_out, err_out, run_out, used_rccl);
+    if (!rc && rounds_out) *rounds_out = h->last_rounds;
+    return rc;
 }
 
 }  // extern "C"

@@ -533,6 +533,31 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 // f right after): the values of layer lam are written (the later g-visit of lam+1 needs
                 // them) but NOT re-read from HBM for the f-visit of lam+1. Only when the source of lam
                 // is HBM-resident (channel LLRs or a scratch layer).
+#ifdef POLAR_SLOTHIST
+                // Measurement build (tools/slot_histogram.py; round-3 verdict item 2): for every visit whose SOURCE layer is
+                // HBM-resident, how many DISTINCT source slots the active paths of a codeword read (pL.get(sh + 1)) — per
+                // visit kind (f / g) and layer size. An f-visit whose source slots coincide would compute and store identical
+                // rows. hist[kind][sh][distinct] += 1, plus sum of active paths and of paths reading their OWN slot.
+                if (GS == 32 && lam > 1 && 2 * S > SL && p.pm_out) {
+                    LANE_CTX
+                    const bool in_pre_ = p.prefix_q > 0 && 2 * S >= p.prefix_q && phi < 2 * S;
+                    const bool tab_ = tbl && lam == 3 && phi >= S2;
+                    if (!in_pre_ && !tab_) {
+                        const int pin_ = pL.get(sh + 1);
+                        int d0 = 0, d1 = 0;
+                        for (int s_ = 0; s_ < 32; ++s_) {
+                            const u64 m_ = __ballot(active && pin_ == s_);
+                            d0 += (m_ & 0xFFFFFFFFull) != 0; d1 += (m_ >> 32) != 0;
+                        }
+                        const u64 own_ = __ballot(active && pin_ == lig);
+                        u64 *hb = reinterpret_cast<u64 *>(p.pm_out) + 64 + (size_t)((odd ? 1 : 0) * 12 + sh) * 40;
+                        if (lane == 0) {
+                            if (actw & 0xFFFFFFFFull) { atomicAdd(hb + d0, 1ull); atomicAdd(hb + 34, (u64)__popcll(actw & 0xFFFFFFFFull)); atomicAdd(hb + 35, (u64)__popcll(own_ & 0xFFFFFFFFull)); }
+                            if (actw >> 32) { atomicAdd(hb + d1, 1ull); atomicAdd(hb + 34, (u64)__popcll(actw >> 32)); atomicAdd(hb + 35, (u64)__popcll(own_ >> 32)); }
+                        }
+                    }
+                }
+#endif
                 if (!PIPE && S >= 8 && 2 * S > SL && lam + 1 <= lam_stop && ((phi >> (sh - 1)) & 1) == 0) {   // (lam+1 is an f-visit)
                     const int H = S / 2;
 #ifdef POLAR_NO_FUSED4
@@ -742,6 +767,12 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     }
                     wave_mem_fence();
                     PROF(odd ? 1 : 2)
+#ifdef POLAR_SLOTHIST
+                    if (GS == 32 && p.pm_out && lane == 0 && actw) {      // f-visits of this pass fed from registers (the path's own values)
+                        u64 *hb = reinterpret_cast<u64 *>(p.pm_out) + 64 + (size_t)24 * 40;
+                        for (int d_ = 1; d_ <= (deep ? 3 : 1); ++d_) if ((S >> d_) > SL) atomicAdd(hb + (sh - d_), 1ull);
+                    }
+#endif
                     lam += deep ? 3 : 1;          // layers lam+1 (.. lam+3) are done
                     continue;
                 }
@@ -1372,7 +1403,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         // (Found by tools/fuzz_parity.py; this read used to return whatever an earlier codeword left in the slot.)
         const bool win_active = __shfl((int)active, gbase + win, 64) != 0;
         if (valid) {
-#ifndef POLAR_PROFILE
+#if !defined(POLAR_PROFILE) && !defined(POLAR_SLOTHIST)
             if (p.pm_out && lig == 0) p.pm_out[cw] = pm_win;
 #endif
         }

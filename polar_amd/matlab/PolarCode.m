@@ -87,15 +87,18 @@ classdef PolarCode < handle
             % llr may be 1 x N or B x N (one codeword per row): rows are decoded as one GPU batch
             u = double(polar_mex('decode_scl_llr', obj.h, double(llr), list_size));
         end
-        function [bler, ber] = get_bler_quick(obj, ebno_vec, list_size_vec, max_runs, max_err, seed, devices)
+        function [bler, ber] = get_bler_quick(obj, ebno_vec, list_size_vec, max_runs, max_err, seed, devices, constellation_id)
             % [bler, ber] indexed (i_ebno, i_list) as PolarM (:781-850); PolarM constants max_err=50, max_runs=500
             % (:788-789); ber = bit errors per run as the reference computes it (:848). devices (optional): GPU
-            % ids to shard the trials over (one process, RCCL all-reduce of the counters).
+            % ids to shard the trials over (one process, RCCL all-reduce of the counters). constellation_id (optional):
+            % 0 = BPSK, ebno_vec in dB; 1/2/3 = 4/8/16-ASK Gray with BICM, ebno_vec read as the SNR axis in dB
+            % (the sweep of main_MC_CC_Comparison.m:44-119).
             if nargin < 4, max_runs = 500; end
             if nargin < 5, max_err = 50; end
             if nargin < 6, seed = 1; end
             if nargin < 7, devices = []; end
-            [b, e] = polar_mex('get_bler_quick', obj.h, double(ebno_vec(:)'), uint8(list_size_vec(:)'), max_runs, max_err, seed, int32(devices));
+            if nargin < 8, constellation_id = 0; end
+            [b, e] = polar_mex('get_bler_quick', obj.h, double(ebno_vec(:)'), uint8(list_size_vec(:)'), max_runs, max_err, seed, int32(devices), constellation_id);
             bler = b';      % gateway returns [n_L x n_e] (PolarC layout); PolarM indexes (ebno, list)
             ber = e';
         end

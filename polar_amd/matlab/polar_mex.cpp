@@ -11,7 +11,7 @@
 #include "polar_amd.h"
 
 static void check(int rc) {
-    if (rc != POLAR_OK) mexErrMsgIdAndTxt("polar_amd:error", "%s", polar_last_error());
+    if (rc < 0) mexErrMsgIdAndTxt("polar_amd:error", "%s", polar_last_error());
 }
 static polar_code_t *H(const mxArray *a) { return (polar_code_t *)(uintptr_t)(*(uint64_t *)mxGetData(a)); }
 
@@ -149,18 +149,19 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         plhs[0] = mxCreateDoubleMatrix(1, K, mxREAL);
         check(polar_decode_sc_p1(h, mxGetPr(prhs[2]), mxGetPr(plhs[0])));
     } else if (c == "get_bler_quick") {
-        // [bler, ber] = polar_mex('get_bler_quick', h, ebno(1 x n_e), L(uint8 1 x n_L), max_runs, max_err, seed [, devices(int32)])
-        // both outputs n_L x n_e (PolarC layout); with a device list the trials are sharded over those GPUs
+        // [bler, ber] = polar_mex('get_bler_quick', h, axis(1 x n_e), L(uint8 1 x n_L), max_runs, max_err, seed [, devices(int32) [, constellation_id]])
+        // both outputs n_L x n_e (PolarC layout); with a device list the trials are sharded over those GPUs; constellation_id
+        // 0 = BPSK with the Eb/N0 axis, POLAR_CONST_ASK*_GRAY = the BICM sweep with the SNR axis (main_MC_CC_Comparison.m:44-119)
         int n_e = (int)mxGetNumberOfElements(prhs[2]), n_L = (int)mxGetNumberOfElements(prhs[3]);
         long max_runs = (long)mxGetScalar(prhs[4]), max_err = (long)mxGetScalar(prhs[5]);
         uint64_t seed = (uint64_t)mxGetScalar(prhs[6]);
         std::vector<double> b((size_t)n_e * n_L), e((size_t)n_e * n_L);
-        if (nrhs > 7 && mxGetNumberOfElements(prhs[7]) > 0)
-            check(polar_get_bler_quick_multi(h, (const int *)mxGetData(prhs[7]), (int)mxGetNumberOfElements(prhs[7]), mxGetPr(prhs[2]), n_e,
-                                             (const uint8_t *)mxGetData(prhs[3]), n_L, max_runs, max_err, seed, 0, b.data(), e.data(), nullptr));
-        else
-            check(polar_get_bler_quick_ber(h, mxGetPr(prhs[2]), n_e, (const uint8_t *)mxGetData(prhs[3]), n_L, max_runs,
-                                           max_err, seed, 0, b.data(), e.data()));
+        const bool have_devs = nrhs > 7 && mxGetNumberOfElements(prhs[7]) > 0;
+        const int constellation = nrhs > 8 ? (int)mxGetScalar(prhs[8]) : 0;
+        check(polar_get_bler_quick_multi_ex(h, constellation, have_devs ? (const int *)mxGetData(prhs[7]) : nullptr,
+                                            have_devs ? (int)mxGetNumberOfElements(prhs[7]) : 1, mxGetPr(prhs[2]), n_e,
+                                            (const uint8_t *)mxGetData(prhs[3]), n_L, max_runs, max_err, seed, 0, b.data(), e.data(),
+                                            nullptr, nullptr, nullptr, nullptr));
         plhs[0] = mxCreateDoubleMatrix(n_L, n_e, mxREAL);
         double *d = mxGetPr(plhs[0]);
         for (int l = 0; l < n_L; ++l) for (int i = 0; i < n_e; ++i) d[(size_t)i * n_L + l] = b[(size_t)l * n_e + i];

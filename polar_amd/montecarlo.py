@@ -5,7 +5,9 @@ workload is counter-based (include/polar_synth.h), the union of trials — and t
 counter — is independent of the world size. The only communication is one all-reduce (sum, int64)
 of the 2*n_L*n_e error/run counters per round (RCCL over xGMI when the backend is "nccl"); the
 early stop `num_err > max_err` (PolarCode.cpp:725) is evaluated on the reduced counters between
-rounds of `global_batch` trials.
+rounds of `global_batch` trials (default: the native driver's geometric rounds, up to 262144 trials
+PER RANK and round — polar_host.cpp next_round(); the two drivers then take the same rounds and
+return the same counters).
 """
 import numpy as np
 
@@ -23,23 +25,35 @@ def _world():
     return 0, 1
 
 
+def next_round(batch, max_err, done, max_runs, world):
+    """Trials of the next round over all ranks: polar_host.cpp next_round() (fixed `batch`, or geometric: first
+    max(256, 2 max_err) rounded up to a multiple of the world size, then as many as all rounds before, at most 262144
+    per rank)."""
+    if batch:
+        t = batch
+    elif done == 0:
+        t = max(256, 2 * max_err)
+        t = -(-t // world) * world
+    else:
+        t = min(done, 262144 * world)
+    return min(t, max_runs - done)
+
+
 def get_bler_quick_sharded(engine, ebno_vec, list_size_vec, max_runs=1000, max_err=100, seed=1,
-                           global_batch=None, device=None):
+                           global_batch=None, device=None, stats=None):
     """engine(seed, t0, T, stride, ebno, Ls, enabled, err, run): adds this rank's counts into the
-    uint64 arrays err/run — polar_amd.PolarCode.mc_batch on a GPU. Returns (bler, err, run)."""
+    uint64 arrays err/run — polar_amd.PolarCode.mc_batch on a GPU. Returns (bler, err, run).
+    global_batch=None / 0: geometric rounds (next_round). stats (optional dict) receives "rounds"."""
     rank, world = _world()
     ebno = np.ascontiguousarray(ebno_vec, np.float64)
     Ls = np.ascontiguousarray(list_size_vec, np.uint8)
     P = (len(Ls), len(ebno))
-    if global_batch is None:
-        global_batch = max_runs
-    if global_batch % world:
-        raise ValueError("global_batch must be a multiple of the world size")
     err = np.zeros(P, np.uint64)
     run = np.zeros(P, np.uint64)
     base = 0
+    rounds = 0
     while base < max_runs:
-        gb = min(global_batch, max_runs - base)
+        gb = next_round(global_batch or 0, max_err, base, max_runs, world)
         enabled = (err <= np.uint64(max_err)).astype(np.uint8)            # PolarCode.cpp:725
         if not enabled.any():
             break
@@ -59,6 +73,9 @@ def get_bler_quick_sharded(engine, ebno_vec, list_size_vec, max_runs=1000, max_e
         err += d_err
         run += d_run
         base += gb
+        rounds += 1
+    if stats is not None:
+        stats["rounds"] = rounds
     bler = np.where(run > 0, err.astype(np.float64) / np.maximum(run, 1).astype(np.float64), 0.0)
     return bler, err, run
 

@@ -144,3 +144,59 @@ def test_weak_unfrozen_leaves_are_classified_at_creation(built_lib):
     assert weak(polar_amd.PolarCode(10, 1022, 0.32, 0)) > 300
     counts = G.load()[0]["cfg5_n10_k512_ask16/counts"]
     assert weak(polar_amd.PolarCode.from_counts(counts, 512)) == 1
+
+
+def test_explicit_tables_with_weak_leaves_return_a_status_not_an_error(built_lib):
+    """polar_create_explicit accepts a table that leaves unfrozen leaves in the worst synthetic channels (the reference does
+    too) but says so: POLAR_W_WEAK_LEAVES, a positive non-error status with a valid handle (the Python mirror turns it into a
+    PolarWeakLeavesWarning); ordinary tables return POLAR_OK."""
+    import warnings
+    import polar_amd
+    L = polar_amd.lib()
+    src = polar_amd.PolarCode(9, 505, 0.7, 0)                     # K = 505 of 512 at eps 0.7: > 100 weak leaves
+    fr, od = src.frozen_bits, src.channel_order_descending
+    h = C.c_void_p()
+    rc = L.polar_create_explicit(C.c_int(9), C.c_int(505), C.c_int(0), fr.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                 od.ctypes.data_as(C.POINTER(C.c_uint16)), None, C.byref(h))
+    assert rc == polar_amd.POLAR_W_WEAK_LEAVES == 1 and h.value
+    assert b"unfrozen leaves" in L.polar_last_error()
+    L.polar_debug_weak_leaves.restype = C.c_int
+    assert L.polar_debug_weak_leaves(h) == src.weak_leaves > 100
+    L.polar_destroy(h)
+    with pytest.warns(polar_amd.PolarWeakLeavesWarning):
+        g = polar_amd.PolarCode.from_tables(9, 505, 0, fr, od)
+    assert g.weak_leaves == src.weak_leaves
+    ok = polar_amd.PolarCode(9, 256, 0.32, 0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        g2 = polar_amd.PolarCode.from_tables(9, 256, 0, ok.frozen_bits, ok.channel_order_descending)
+    assert g2.weak_leaves == 0
+
+
+def test_environment_knobs_are_read_once_and_validated(built_lib, monkeypatch):
+    """POLAR_MODE & co. are measurement knobs: read when a handle is created (never inside a decode), and validated — an
+    out-of-range value fails the creation instead of silently selecting a kernel path. polar_debug_set validates too, and the
+    fault-injection hooks have no environment form."""
+    import polar_amd
+    monkeypatch.setenv("POLAR_MODE", "7")
+    with pytest.raises(polar_amd.PolarError, match="POLAR_MODE"):
+        polar_amd.PolarCode(5, 16, 0.32, 0)
+    monkeypatch.setenv("POLAR_MODE", "2")
+    g = polar_amd.PolarCode(5, 16, 0.32, 0)
+    assert g.debug_get("mode_override") == 2
+    monkeypatch.setenv("POLAR_MODE", "1")                          # (appears later: the existing handle keeps what it read)
+    assert g.debug_get("mode_override") == 2
+    monkeypatch.delenv("POLAR_MODE")
+    g2 = polar_amd.PolarCode(5, 16, 0.32, 0)
+    assert g2.debug_get("mode_override") == -1
+    with pytest.raises(polar_amd.PolarError):
+        g2.debug_set("mode_override", 3)
+    with pytest.raises(polar_amd.PolarError, match="unknown key"):
+        g2.debug_set("no_such_knob", 1)
+    for k in ("share_device", "fail_device", "fail_collective", "force_rccl", "no_rccl", "sc_no_fold", "no_tables"):
+        g2.debug_set(k, 1)
+    src = open(os.path.join(ROOT, "polar_amd", "csrc", "polar_host.cpp")).read()
+    body = src[src.index("int read_env_knobs("):]
+    body = body[:body.index("\n}\n")]
+    assert src.count("getenv(") == body.count("getenv(") > 0      # every getenv of the library sits in read_env_knobs
+    assert "FAIL" not in body and "SHARE" not in body              # (no environment form of the test hooks)

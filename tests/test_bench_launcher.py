@@ -23,6 +23,14 @@ def test_plain_launch_with_gpus_2_runs_two_ranks():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["dry_run"] is True
     assert line["runs_all_ranks"] == 2 * 2 * 262144          # both ranks' shards reached the reduction
+    # the end-to-end Monte-Carlo leg (strong scaling: the total is fixed, rounds of 262144 trials per rank, one counter
+    # all-reduce per round), with a stand-in engine: both ranks' strided shards reach every round's reduction and the
+    # sharded counters of the prefix equal the unsharded ones
+    mc = line["monte_carlo"]
+    assert mc["n_gpus"] == 2 and mc["total_trials"] == 4194304
+    assert mc["multiprocess"]["rounds"] == 4194304 // (2 * 262144)
+    assert mc["multiprocess"]["runs"] == [4194304] * 5 and mc["mc_trials_per_s"] > 0
+    assert mc["counters_equal_single_gpu"] is True and mc["counters_equal_single_gpu_detail"]["multiprocess"] is True
 
 
 def test_world_size_and_gpus_must_agree():

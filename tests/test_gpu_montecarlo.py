@@ -62,33 +62,41 @@ def test_multi_gpu_entry_point_one_device_through_rccl(built_lib, oracle_built):
     o, g = _pair(9, 256, 8)
     ebno, Ls = [1.0, 2.0, 3.0], [1, 8]
     want, want_ber = g.get_bler_quick(ebno, Ls, max_runs=600, max_err=40, seed=9, batch=200, return_ber=True)
-    os.environ["POLAR_FORCE_RCCL"] = "1"
-    try:
-        got, got_ber = g.get_bler_quick(ebno, Ls, max_runs=600, max_err=40, seed=9, batch=200, return_ber=True, devices=[0])
-        used = g.last_used_rccl
-    finally:
-        del os.environ["POLAR_FORCE_RCCL"]
+    g.debug_set("force_rccl", 1)
+    got, got_ber = g.get_bler_quick(ebno, Ls, max_runs=600, max_err=40, seed=9, batch=200, return_ber=True, devices=[0])
+    used = g.last_used_rccl
+    g.debug_set("force_rccl", 0)
     assert used, "RCCL could not be loaded/initialised on the GPU box"
     assert (got == want).all() and (got_ber == want_ber).all()
     # and the host-sum fallback
+    g.debug_set("no_rccl", 1)
+    got2 = g.get_bler_quick(ebno, Ls, max_runs=600, max_err=40, seed=9, batch=200, devices=[0])
+    assert not g.last_used_rccl
+    g.debug_set("no_rccl", 0)
+    assert (got2 == want).all()
+    # the environment form of the knobs is read once, at handle creation: a variable that appears later changes nothing
     os.environ["POLAR_NO_RCCL"] = "1"
     try:
-        got2 = g.get_bler_quick(ebno, Ls, max_runs=600, max_err=40, seed=9, batch=200, devices=[0])
-        assert not g.last_used_rccl
+        g.debug_set("force_rccl", 1)
+        g.get_bler_quick(ebno, Ls, max_runs=200, max_err=40, seed=9, batch=200, devices=[0])
+        assert g.last_used_rccl
+        o2, g2 = _pair(9, 256, 8)                   # (a handle created with the variable set takes it)
+        g2.debug_set("force_rccl", 1)
+        g2.get_bler_quick(ebno, Ls, max_runs=200, max_err=40, seed=9, batch=200, devices=[0])
+        assert not g2.last_used_rccl
     finally:
         del os.environ["POLAR_NO_RCCL"]
-    assert (got2 == want).all()
 
 
 def test_multi_device_partition_with_one_gpu_standing_in_for_several(built_lib, oracle_built, monkeypatch):
     """The single-process multi-GPU driver (per-device table clones, one worker thread and stream per device, trials
     done + d, done + d + n_dev, ..., counter sum) with ONE GPU listed two / three / five times (test hook
-    POLAR_TEST_SHARE_DEVICE; RCCL cannot have two ranks on a device, so the counters are summed on the host): the
+    "share_device"; RCCL cannot have two ranks on a device, so the counters are summed on the host): the
     estimates must be those of the single-device run — the union of the trials does not depend on the partition."""
     o, g = _pair(8, 128, 8)
     ebno, Ls = [0.5, 2.0], [1, 4, 8]
     want, want_ber = g.get_bler_quick(ebno, Ls, max_runs=1500, max_err=60, seed=77, batch=250, return_ber=True)
-    monkeypatch.setenv("POLAR_TEST_SHARE_DEVICE", "1")
+    g.debug_set("share_device", 1)
     for devs in ([0, 0], [0, 0, 0], [0] * 5):
         got, got_ber = g.get_bler_quick(ebno, Ls, max_runs=1500, max_err=60, seed=77, batch=250, return_ber=True, devices=devs)
         assert np.array_equal(np.asarray(got), np.asarray(want)), devs
@@ -110,7 +118,7 @@ def test_communicators_and_streams_are_cached_on_the_handle(built_lib, monkeypat
     L = polar_amd.lib()
     L.polar_debug_comm_inits.restype = C.c_int
     o, g = _pair(8, 128, 8)
-    monkeypatch.setenv("POLAR_FORCE_RCCL", "1")
+    g.debug_set("force_rccl", 1)
     n0 = L.polar_debug_comm_inits()
     a = g.get_bler_quick([1.0, 2.0], [1, 4], max_runs=400, max_err=30, seed=3, batch=100, devices=[0])
     assert g.last_used_rccl, "RCCL could not be loaded/initialised on the GPU box"
@@ -127,14 +135,97 @@ def test_a_failing_device_aborts_the_round_for_every_device(built_lib, monkeypat
     handle works again afterwards."""
     import polar_amd
     o, g = _pair(8, 128, 8)
-    monkeypatch.setenv("POLAR_TEST_SHARE_DEVICE", "1")
+    g.debug_set("share_device", 1)
     want = g.get_bler_quick([1.0], [1, 4], max_runs=900, max_err=10**6, seed=3, batch=300, devices=[0, 0, 0])
-    monkeypatch.setenv("POLAR_TEST_FAIL_DEVICE", "1")
-    with pytest.raises(polar_amd.PolarError, match="injected failure"):
+    g.debug_set("fail_device", 1)
+    with pytest.raises(polar_amd.PolarError, match=r"device 0: injected failure \(fail_device\)"):
         g.get_bler_quick([1.0], [1, 4], max_runs=900, max_err=10**6, seed=3, batch=300, devices=[0, 0, 0])
-    monkeypatch.delenv("POLAR_TEST_FAIL_DEVICE")
+    g.debug_set("fail_device", -1)
     again = g.get_bler_quick([1.0], [1, 4], max_runs=900, max_err=10**6, seed=3, batch=300, devices=[0, 0, 0])
     assert np.array_equal(np.asarray(again), np.asarray(want))
+
+
+def test_a_failing_collective_enqueue_aborts_before_anyone_synchronises(built_lib):
+    """Worker 2 of three gets past the barrier that precedes the counter reduction and THEN fails (its collective enqueue,
+    test hook "fail_collective"): its peers have their share of the collective on their streams and would wait in
+    hipStreamSynchronize for a rank that never arrives. Every worker meets again after the enqueue and, since one failed,
+    aborts its own communicator before synchronising; the call returns the error (naming the device that failed first-hand)
+    and the next call rebuilds communicators and worker threads. Host-sum form with a shared device, and the RCCL form with
+    one rank (the communicator is aborted and a new ncclCommInitAll happens on the next call)."""
+    import polar_amd
+    o, g = _pair(8, 128, 8)
+    g.debug_set("share_device", 1)
+    want = g.get_bler_quick([1.0], [1, 4], max_runs=900, max_err=10**6, seed=3, batch=300, devices=[0, 0, 0])
+    t0 = g.debug_get("worker_threads_started")
+    g.debug_set("fail_collective", 2)
+    with pytest.raises(polar_amd.PolarError, match=r"injected failure \(fail_collective\)"):
+        g.get_bler_quick([1.0], [1, 4], max_runs=900, max_err=10**6, seed=3, batch=300, devices=[0, 0, 0])
+    g.debug_set("fail_collective", -1)
+    again = g.get_bler_quick([1.0], [1, 4], max_runs=900, max_err=10**6, seed=3, batch=300, devices=[0, 0, 0])
+    assert np.array_equal(np.asarray(again), np.asarray(want))
+    assert g.debug_get("worker_threads_started") == t0 + 3          # the pool of the failed context was torn down, one new pool
+    g.debug_set("share_device", 0)
+    g.debug_set("force_rccl", 1)
+    one = g.get_bler_quick([1.0], [1, 4], max_runs=900, max_err=10**6, seed=3, batch=300, devices=[0])
+    assert g.last_used_rccl and np.array_equal(np.asarray(one), np.asarray(want))
+    n0 = g.debug_get("comm_inits")
+    g.debug_set("fail_collective", 0)
+    with pytest.raises(polar_amd.PolarError, match="fail_collective"):
+        g.get_bler_quick([1.0], [1, 4], max_runs=900, max_err=10**6, seed=3, batch=300, devices=[0])
+    g.debug_set("fail_collective", -1)
+    two = g.get_bler_quick([1.0], [1, 4], max_runs=900, max_err=10**6, seed=3, batch=300, devices=[0])
+    assert g.last_used_rccl and np.array_equal(np.asarray(two), np.asarray(want))
+    assert g.debug_get("comm_inits") == n0 + 1
+
+
+def test_worker_threads_live_on_the_handle_between_calls(built_lib):
+    """One thread per device, created with the device list's context and parked between rounds and calls (round 3 created
+    and joined n_dev threads per ROUND)."""
+    o, g = _pair(8, 128, 0)
+    g.debug_set("share_device", 1)
+    a, ca = g.get_bler_quick([1.0, 3.0], [1], max_runs=4000, max_err=10**6, seed=4, batch=500, devices=[0] * 4, return_counters=True)
+    assert ca["rounds"] == 8 and g.debug_get("worker_threads_started") == 4
+    b = g.get_bler_quick([1.0, 3.0], [1], max_runs=4000, max_err=10**6, seed=4, batch=500, devices=[0] * 4)
+    assert g.debug_get("worker_threads_started") == 4 and np.array_equal(a, b)
+    g.get_bler_quick([1.0], [1], max_runs=500, max_err=10**6, seed=4, batch=500, devices=[0] * 2)     # another list: another pool
+    assert g.debug_get("worker_threads_started") == 6
+
+
+def test_automatic_rounds_grow_with_the_device_count(built_lib):
+    """batch = 0: a round is capped at 262144 trials PER DEVICE (round 3 capped it over all devices: at 8 GPUs each got
+    32768 per round — less than one resident round of the list-size-1 kernel). Five contexts on one GPU, a short code: the
+    last rounds hand every context 262144 trials; one device alone reaches the same cap; and the estimates of the two runs
+    are those of the same trials whenever the run counts agree (no early stop here)."""
+    o, g = _pair(6, 32, 0)
+    total = 3 * 5 * 262144
+    one, c1 = g.get_bler_quick([7.0], [1], max_runs=total, max_err=50000, seed=8, return_counters=True)
+    assert g.debug_get("last_round_max_per_device") == 262144
+    g.debug_set("share_device", 1)
+    five, c5 = g.get_bler_quick([7.0], [1], max_runs=total, max_err=50000, seed=8, devices=[0] * 5, return_counters=True)
+    assert g.debug_get("last_round_max_per_device") == 262144
+    assert c5["rounds"] < c1["rounds"]
+    assert int(c1["run"][0, 0]) == int(c5["run"][0, 0]) == total and int(c1["err"][0, 0]) == int(c5["err"][0, 0]) > 0
+
+
+def test_bicm_sweep_sharded_over_devices_equals_one_device(built_lib, oracle_built):
+    """BASELINE configuration 5's shape behind the native multi-device entry point (polar_get_bler_quick_multi_ex with an
+    ASK Gray constellation: PolarM/main_MC_CC_Comparison.m:44-119): the counters of three contexts equal those of one
+    device, and those of the step-wise engine (polar_mc_batch_bicm) the multi-process driver uses."""
+    o, g = _pair(8, 128, 0)
+    snr, Ls = [9.0, 11.0, 13.0], [1, 8]
+    want, cw = g.get_bler_quick(snr, Ls, max_runs=1200, max_err=80, seed=21, batch=300, constellation="ask16-gray", return_counters=True)
+    assert 0 < want[1, 2] < want[1, 0] <= 1
+    g.debug_set("share_device", 1)
+    got, cg = g.get_bler_quick(snr, Ls, max_runs=1200, max_err=80, seed=21, batch=300, constellation="ask16-gray",
+                               devices=[0, 0, 0], return_counters=True)
+    assert np.array_equal(cw["err"], cg["err"]) and np.array_equal(cw["run"], cg["run"]) and cw["rounds"] == cg["rounds"]
+    from polar_amd.montecarlo import get_bler_quick_sharded
+    eng = lambda seed, t0, T, stride, ax, L_, en, e, r: g.mc_batch_bicm("ask16-gray", seed, t0, T, stride, ax, L_, en, e, r)
+    bler, err, run = get_bler_quick_sharded(eng, snr, Ls, max_runs=1200, max_err=80, seed=21, global_batch=300)
+    assert np.array_equal(err, cw["err"]) and np.array_equal(run, cw["run"])
+    # the BPSK sweep is a different workload (same code, Eb/N0 axis)
+    other = g.get_bler_quick(snr, Ls, max_runs=300, max_err=80, seed=21, batch=300)
+    assert not np.array_equal(other, want)
 
 
 def test_python_sharded_driver_and_strided_engine_on_the_gpu(built_lib, oracle_built):

@@ -177,12 +177,13 @@ def test_full_size_roundtrip_config4(built_lib):
     assert torch.equal(out, info)
 
 
-@pytest.mark.parametrize("n,K,crc", [(5, 16, 4), (8, 128, 0), (10, 512, 8)])
+@pytest.mark.parametrize("n,K,crc", [(5, 16, 4), (8, 128, 0), (10, 512, 8), (11, 1024, 16)])
 @pytest.mark.parametrize("L", [1, 4, 8, 32])
 def test_decode_scl_p1_matches_oracle(built_lib, oracle_built, n, K, crc, L):
-    """Probability-domain SCL (PolarCode.cpp:110-128, 375-420) incl. the cross-path normalisation."""
+    """Probability-domain SCL (PolarCode.cpp:110-128, 375-420) incl. the cross-path normalisation; n = 11 is the headline
+    code (N = 2048, K = 1024, CRC 16) in the probability domain."""
     o, g = _pair(n, K, crc)
-    llr, _ = o.synth_llr(2222, 0, 24, o.snr_sqrt_linear(2.0))
+    llr, _ = o.synth_llr(2222, 0, 24 if n < 11 else 12, o.snr_sqrt_linear(2.0))
     p1 = 1.0 / (1.0 + np.exp(llr))
     p0 = 1.0 - p1
     got = g.decode_scl_p1(p1, p0, L)
@@ -317,9 +318,9 @@ def test_list_size_one_reads_the_callers_rows_in_place(built_lib, oracle_built, 
     llr[7] = -llr[7]
     want = o.decode_scl_llr(llr, 1)
     got = g.decode_scl_llr(llr, 1)
-    monkeypatch.setenv("POLAR_SC_NO_FOLD", "1")
+    g.debug_set("sc_no_fold", 1)
     got_front = g.decode_scl_llr(llr, 1)
-    monkeypatch.delenv("POLAR_SC_NO_FOLD")
+    g.debug_set("sc_no_fold", 0)
     assert (got == want).all() and (got_front == want).all()
     f = llr.astype(np.float32)
     want32 = o.decode_scl_llr(f.astype(np.float64), 1)
@@ -404,3 +405,63 @@ def test_reserve_presizes_the_scratch(built_lib, oracle_built):
     llr, _ = o.synth_llr(9, 0, 700, o.snr_sqrt_linear(2.0))
     for L in (1, 4, 32):
         assert (g.decode_scl_llr(llr, L) == o.decode_scl_llr(llr, L)).all(), L
+
+
+def test_reserve_means_no_allocation_inside_the_asynchronous_calls(built_lib, oracle_built):
+    """After polar_reserve(B, L) the device-resident decodes within (B, L) — every list size 1 .. L (the list-size-1 kernel
+    with its flag words and scratch, the 2-lane groups, every lane group up to L), doubles and floats, with and without the
+    path-metric output — make NO hipMalloc / hipFree (an implicit device synchronisation inside a nominally asynchronous
+    call): asserted on the library's allocation counter. A larger batch then does allocate (the counter works)."""
+    import torch
+    o, g = _pair(9, 256, 8)
+    B = 2500
+    g.reserve(B, 32)
+    llr = torch.empty((B, 512), dtype=torch.float64, device="cuda")
+    g.synth_llr_dev(3, 0, B, g.snr_sqrt_linear(2.0), llr.data_ptr())
+    f32 = llr.to(torch.float32)
+    out = torch.empty((B, 256), dtype=torch.uint8, device="cuda")
+    pm = torch.empty(B, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    a0 = g.debug_get("allocs")
+    for L in (32, 1, 2, 3, 4, 7, 8, 16, 17, 31):
+        for b in (B, B // 3, 1):
+            g.decode_scl_llr_dev(llr.data_ptr(), b, L, out.data_ptr())
+            g.decode_scl_llr_dev(llr.data_ptr(), b, L, out.data_ptr(), pm_ptr=pm.data_ptr())
+            g.decode_scl_llr_dev_f32(f32.data_ptr(), b, L, out.data_ptr())
+    torch.cuda.synchronize()
+    assert g.debug_get("allocs") == a0
+    big = torch.empty((2 * B, 512), dtype=torch.float64, device="cuda")
+    g.synth_llr_dev(3, 0, 2 * B, g.snr_sqrt_linear(2.0), big.data_ptr())
+    out2 = torch.empty((2 * B, 256), dtype=torch.uint8, device="cuda")
+    g.decode_scl_llr_dev(big.data_ptr(), 2 * B, 8, out2.data_ptr())
+    torch.cuda.synchronize()
+    assert g.debug_get("allocs") > a0
+
+
+def test_list_size_one_accepts_rows_that_are_not_16_byte_aligned(built_lib, oracle_built):
+    """The in-place channel reads of the list-size-1 kernel are 16-byte vector loads; a caller's pointer with only the
+    natural alignment of its element type (a view into a larger buffer, offset by one double / one float) is decoded through
+    the converted copy instead: same bits."""
+    import torch
+    o, g = _pair(11, 1024, 0)
+    B = 40
+    llr, _ = o.synth_llr(17, 0, B, o.snr_sqrt_linear(2.0))
+    want = o.decode_scl_llr(llr, 1)
+    buf = torch.zeros(B * 2048 + 3, dtype=torch.float64, device="cuda")
+    out = torch.empty((B, 1024), dtype=torch.uint8, device="cuda")
+    for off in (0, 1):
+        v = buf[off: off + B * 2048]
+        v.copy_(torch.from_numpy(llr.reshape(-1)))
+        assert v.data_ptr() % 16 == 8 * off
+        g.decode_scl_llr_dev(v.data_ptr(), B, 1, out.data_ptr())
+        torch.cuda.synchronize()
+        assert (out.cpu().numpy() == want).all(), off
+    f = llr.astype(np.float32)
+    want32 = o.decode_scl_llr(f.astype(np.float64), 1)
+    buf32 = torch.zeros(B * 2048 + 5, dtype=torch.float32, device="cuda")
+    for off in (0, 1, 2, 3):
+        v = buf32[off: off + B * 2048]
+        v.copy_(torch.from_numpy(f.reshape(-1)))
+        g.decode_scl_llr_dev_f32(v.data_ptr(), B, 1, out.data_ptr())
+        torch.cuda.synchronize()
+        assert (out.cpu().numpy() == want32).all(), off

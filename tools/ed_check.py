@@ -30,9 +30,9 @@ for (n, K, crc, L) in CODES:
     o2 = torch.empty((Bp, K), dtype=torch.uint8, device="cuda")
     for ebno in (0.5, 1.5, 2.0, 3.0, 6.0):
         g.synth_llr_dev(4242, 0, Bp, g.snr_sqrt_linear(ebno), d_llr.data_ptr())
-        os.environ["POLAR_MODE"] = "1"
+        g.set_mode(1)
         g.decode_scl_llr_dev(d_llr.data_ptr(), Bp, L, o1.data_ptr())
-        os.environ["POLAR_MODE"] = "2"
+        g.set_mode(2)
         g.decode_scl_llr_dev(d_llr.data_ptr(), Bp, L, o2.data_ptr())
         torch.cuda.synchronize()
         bad = int((o1 != o2).any(dim=1).sum())
@@ -49,7 +49,7 @@ d_llr = torch.empty((Bt, 2048), dtype=torch.float64, device="cuda")
 o1 = torch.empty((Bt, 1024), dtype=torch.uint8, device="cuda")
 g.synth_llr_dev(4242, 0, Bt, g.snr_sqrt_linear(2.0), d_llr.data_ptr())
 for mode in ("1", "2", "1", "2"):
-    os.environ["POLAR_MODE"] = mode
+    g.set_mode(int(mode))
     g.decode_scl_llr_dev(d_llr.data_ptr(), Bt, 32, o1.data_ptr())
     torch.cuda.synchronize()
     t0 = time.time()
