@@ -123,6 +123,7 @@ struct polar_code {
         int fail_device = -1;        // (test hook) this worker reports a failure in its second round, before the collective
         int fail_collective = -1;    // (test hook) this worker's collective enqueue "fails" in its second round (after the barrier)
         long multi_timeout_s = 1800; // watchdog of a multi-device round: communicators are aborted when a round takes longer
+        long lat_max_b = 0;          // batches up to this size take the one-codeword-per-wave kernels (0 = default, -1 = never)
     } knobs;
     // Monte-Carlo engine (device side): alive lists (double-buffered), their lengths, per-round counters
     DevBuf<uint64_t> d_alive[2];
@@ -481,11 +482,13 @@ int polar_debug_set(polar_code_t *h, const char *key, long value) {
     if (s == "mode_override") { if (value < -1 || value > 2) return fail(POLAR_E_ARG, "mode_override must be -1 (none), 0, 1 or 2"); k.mode_override = (int)value; }
     else if (s == "sc_no_fold") k.sc_no_fold = value != 0;
     else if (s == "no_tables") k.no_tables = value != 0;
+    else if (s == "no_prefix") h->prefix_on = (value == 0);          // (the all-frozen prefix decoded leaf by leaf by the list kernel itself)
     else if (s == "no_rccl") k.no_rccl = value != 0;
     else if (s == "force_rccl") k.force_rccl = value != 0;
     else if (s == "share_device") k.share_device = value != 0;
     else if (s == "fail_device") k.fail_device = (int)value;
     else if (s == "fail_collective") k.fail_collective = (int)value;
+    else if (s == "lat_max_b") k.lat_max_b = value;
     else if (s == "multi_timeout_s") { if (value < 0) return fail(POLAR_E_ARG, "multi_timeout_s must be >= 0 (0 = no watchdog)"); k.multi_timeout_s = value; }
     else return fail(POLAR_E_ARG, "polar_debug_set: unknown key '%s'", key);
     drop_clones(h);          // (the per-device contexts carry a copy of the knobs)
@@ -638,7 +641,10 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
         // (the in-place reads are 16-byte vector loads: a caller's pointer that is not 16-byte aligned takes the front pass; the knob:
         // A/B measurements and the parity tests of both paths)
         const bool fold = h->sc_fold && !h->knobs.sc_no_fold && ((uintptr_t)d_llr & 15u) == 0;
-        if (!fold && (rc = h->d_ech.ensure((size_t)B * h->N))) return rc;
+        // small batches: one codeword per wave, whole state in LDS (sc_lat_kernel: a lone wave of the eight-codeword kernel pays
+        // a memory round trip per dependent access of its HBM-resident layers — B = 1: 0.85 ms against 0.33 ms on a host core)
+        const bool lat = h->n <= polar_sc_lat_max_log() && h->knobs.lat_max_b >= 0 && B <= (h->knobs.lat_max_b ? h->knobs.lat_max_b : 2048);
+        if (!fold && !lat && (rc = h->d_ech.ensure((size_t)B * h->N))) return rc;
         if ((rc = h->d_flags.ensure((size_t)B))) return rc;
         if ((rc = h->d_list.ensure((size_t)B))) return rc;
         if ((rc = h->d_count.ensure(1))) return rc;
@@ -649,15 +655,16 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
         HIP_TRY(hipMemsetAsync(h->d_flag_words.p, 0, ((size_t)(B + 31) / 32 + 1) * sizeof(unsigned int), st));
         HIP_TRY(hipMemsetAsync(h->d_count.p, 0, sizeof(unsigned int), st));
         HIP_TRY(hipMemsetAsync(p.work, 0, sizeof(unsigned int), st));
-        if (!fold) HIP_TRY(polar_launch_sc8_front(d_llr, llr_f32, h->d_ech.p, h->d_flag_words.p, h->d_tabs.p, h->n, B, n_dev, st));
+        if (!fold && !lat) HIP_TRY(polar_launch_sc8_front(d_llr, llr_f32, h->d_ech.p, h->d_flag_words.p, h->d_tabs.p, h->n, B, n_dev, st));
         PolarScParams sp;
         sp.n = h->n; sp.N = h->N; sp.K = h->K; sp.B = B;
-        sp.llr = fold ? d_llr : nullptr; sp.llr_f32 = llr_f32;
-        sp.ech_t = fold ? nullptr : h->d_ech.p; sp.out = d_out; sp.ops = h->d_sc_ops.p; sp.n_ops = (int)h->sc_ops.size();
+        sp.llr = (fold || lat) ? d_llr : nullptr; sp.llr_f32 = llr_f32;
+        sp.ech_t = (fold || lat) ? nullptr : h->d_ech.p; sp.out = d_out; sp.ops = h->d_sc_ops.p; sp.n_ops = (int)h->sc_ops.size();
         sp.order = h->d_order.p; sp.tabs = h->d_tabs.p; sp.a_scr = h->d_llr_scr.p;
         sp.flag_words = h->d_flag_words.p; sp.work = p.work; sp.n_dev = n_dev;
         if (ev_start) HIP_TRY(hipEventRecord((hipEvent_t)ev_start, st));
-        HIP_TRY(polar_launch_sc8_decode(sp, sgrid, st));
+        if (lat) HIP_TRY(polar_launch_sc_lat(sp, (int)std::min<long>(B, (long)h->num_cu * 4), st));
+        else HIP_TRY(polar_launch_sc8_decode(sp, sgrid, st));
         if (ev_stop) HIP_TRY(hipEventRecord((hipEvent_t)ev_stop, st));
         HIP_TRY(polar_launch_sc_flags_expand(h->d_flag_words.p, h->d_flags.p, B, st));
         HIP_TRY(polar_launch_ed_collect(h->d_flags.p, B, n_dev, h->d_list.p, h->d_count.p, st));

@@ -84,6 +84,10 @@ int polar_sc8_min_global_log();          // log2 of the smallest HBM-resident la
 hipError_t polar_launch_sc8_front(const void *llr, int llr_f32, double *ech_p, unsigned int *flag_words, const double *tabs,
                                   int n, long B, const unsigned *n_dev, hipStream_t st);
 hipError_t polar_launch_sc8_decode(const PolarScParams &p, int grid_waves, hipStream_t st);
+// one codeword per wave, whole state in LDS: the latency form for small batches (N <= 2^polar_sc_lat_max_log())
+size_t polar_sc_lat_lds_bytes(int N);
+int polar_sc_lat_max_log();
+hipError_t polar_launch_sc_lat(const PolarScParams &p, int blocks, hipStream_t st);
 hipError_t polar_launch_sc_flags_expand(const unsigned int *flag_words, uint8_t *flags, long B, hipStream_t st);
 
 // Monte-Carlo code construction (polar_construct.hip)

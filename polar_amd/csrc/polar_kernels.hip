@@ -1649,13 +1649,19 @@ __global__ __launch_bounds__(256) void ed_front_kernel(const TIN *llr, double *e
     for (long cw = (long)blockIdx.x * 4 + (threadIdx.x >> 6); cw < B; cw += (long)gridDim.x * 4) {
         const TIN *src = llr + (size_t)cw * N;
         double *dst = ech + (size_t)cw * N;
-        bool any = false;
+        bool any = false, sized = false;
         for (int i = lane; i < N; i += 64) {
             bool f;
-            dst[i] = ed_from_channel((double)src[i], tb, f);
+            const double x = (double)src[i];
+            dst[i] = ed_from_channel(x, tb, f);
             any |= f;
+            sized |= fabs(x) >= 0.1;
         }
-        const bool bad = wave_any(any);
+        // A row whose WHOLE channel is tiny (no |llr| >= 0.1: e.g. LLRs scaled by 1e-3, whose largest values are 0.02 ... 0.03;
+        // an ordinary row has hundreds of values above 1) is decided by the reference at the rounding noise of its own f-chains from the second layer on —
+        // the same class as the per-value guard above, which looks at one value at a time and lets such rows pass. They go to
+        // the LLR-domain kernel, which follows the reference's arithmetic further down (fuzz: 4 of 3 600 such rows differed).
+        const bool bad = wave_any(any) || !wave_any(sized);
         if (lane == 0) flags[cw] = bad ? 1 : 0;
     }
 }

@@ -444,6 +444,217 @@ hipError_t polar_launch_sc8_decode(const PolarScParams &p, int grid_waves, hipSt
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// sc_lat_kernel — list size 1, ONE CODEWORD PER WAVE: the latency form of the pruned SC decoder, for the reference's own
+// call pattern (one codeword per call: PolarCode.cpp:756, PolarM/main_MC_CC_Comparison.m:96) and small batches.
+// sc8_decode_kernel packs eight codewords into a wave and keeps the big layers in a global scratch: right for throughput,
+// but a lone wave then pays a full memory round trip (~2 us) per dependent access of the top layers, and B = 1 costs
+// 0.85 ms against 0.33 ms on one host core. Here the 64 lanes share the ELEMENTS of one codeword (element j in lane
+// j & 63), the whole state lives in LDS (layer of size S at a[S .. 2S), the converted channel at a[N .. 2N): 16 N bytes,
+// 32 KiB at N = 2048) and nothing but the channel row and the K result bytes touches HBM. Same host-built schedule (the
+// folded F steps of an op are unrolled again), same node arithmetic (f_node_e / g_node_e: results bit-identical to
+// sc8_decode_kernel's), same guards -> flag word -> the general kernel in the same call. Nodes of size >= 64 are
+// lane-local (j and j + S share a lane); narrower ones read their partner straight from LDS.
+constexpr int SCLAT_U = 4;
+__global__ __launch_bounds__(64) void sc_lat_kernel(PolarScParams p) {
+    const int lane = threadIdx.x;
+    const int N = p.N, K = p.K;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *tabs = reinterpret_cast<double *>(smem);
+    double *a = tabs + 324;                                           // [2 N]
+    const int words = (N + 31) / 32;
+    uint32_t *bw = reinterpret_cast<uint32_t *>(a + 2 * (size_t)N);   // partial sums, one bit per leaf position
+    uint32_t *uw = bw + words;                                        // decisions
+    for (int i = lane; i < 322; i += 64) tabs[i] = p.tabs[i];
+    wave_mem_fence();
+    const Tabs tb = {tabs, tabs + 64, tabs + 64 + 129};
+    long Bv = p.B;
+    if (p.n_dev && (long)*p.n_dev < Bv) Bv = (long)*p.n_dev;
+    typedef const uint32_t __attribute__((address_space(4))) *kconst_u32;
+    const kconst_u32 ops = (kconst_u32)(uintptr_t)p.ops;
+    for (long cw = blockIdx.x; cw < Bv; cw += gridDim.x) {
+        u64 guard = 0;
+        for (int i = lane; i < words; i += 64) { bw[i] = 0u; uw[i] = 0u; }
+        {   // channel row -> stored form, kernel element order (element e = channel position bitrev_n(e)); input guard as
+            // sc8_front_kernel (ed_from_channel). The loads are coalesced and eight of them are in flight per lane.
+            bool any = false;
+            for (int i0 = 0; i0 < N; i0 += 64 * 8) {
+                double x[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = i0 + 64 * k + lane;
+                    x[k] = (i < N) ? (p.llr_f32 ? (double)reinterpret_cast<const float *>(p.llr)[(size_t)cw * N + i]
+                                                : reinterpret_cast<const double *>(p.llr)[(size_t)cw * N + i]) : 1.0;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = i0 + 64 * k + lane;
+                    bool f;
+                    const double v = ed_from_channel(x[k], tb, f);
+                    any |= f;
+                    if (i < N) a[N + (__brev((unsigned)i) >> (32 - p.n))] = v;
+                }
+            }
+            guard |= __builtin_amdgcn_ballot_w64(any);
+        }
+        wave_mem_fence();
+        // one layer visit: layer of size S = 2^sh from the layer above it (f), or with the partial sums at [base, base + S) (g)
+        auto visit = [&](int type, int sh, int base) {
+            const int S = 1 << sh;
+            const double *src = a + 2 * (size_t)S;
+            double *dst = a + S;
+            if (S >= 64) {
+                for (int j0 = lane; j0 < S; j0 += 64 * SCLAT_U) {
+                    double va[SCLAT_U], vb[SCLAT_U];
+#pragma unroll
+                    for (int k = 0; k < SCLAT_U; ++k) if (j0 + 64 * k < S) { va[k] = src[j0 + 64 * k]; vb[k] = src[j0 + 64 * k + S]; }
+#pragma unroll
+                    for (int k = 0; k < SCLAT_U; ++k) if (j0 + 64 * k < S) {
+                        double y;
+                        if (type == 0) y = f_node_e(va[k], vb[k], guard);
+                        else {
+                            const int jj = base + j0 + 64 * k;
+                            y = g_node_e(va[k], vb[k], bw[jj >> 5] << (31 - (jj & 31)), tb);
+                        }
+                        dst[j0 + 64 * k] = y;
+                    }
+                }
+            } else {
+                const bool in = lane < S;
+                const double va = in ? src[lane] : 0.5, vb = in ? src[lane + S] : 0.5;      // (idle lanes: harmless operands)
+                double y;
+                if (type == 0) y = f_node_e(va, vb, guard);
+                else {
+                    const int jj = base + (in ? lane : 0);
+                    y = g_node_e(va, vb, bw[jj >> 5] << (31 - (jj & 31)), tb);
+                }
+                if (in) dst[lane] = y;
+            }
+            wave_mem_fence();
+        };
+        uint32_t op_next = ops[0];
+        for (int io = 0; io < p.n_ops; ++io) {
+            const uint32_t op = op_next;
+            op_next = ops[io + 1 < p.n_ops ? io + 1 : io];             // (scalar load, one op ahead)
+            const int type = (int)(op & 7u), sh = (int)((op >> 3) & 15u), base = (int)((op >> 8) & 0xFFFFu);
+            const int extra = (int)((op >> 24) & 3u);                   // F steps of the child chain the host folded into this op
+            const int S = 1 << sh;
+            if (type <= 1) {
+                visit(type, sh, base);
+                for (int d = 1; d <= extra; ++d) visit(0, sh - d, base);
+            } else if (type == 3) {
+                // ---- all-unfrozen subtree (see sc8_decode_kernel): hard decisions of its root, the exact-zero and
+                // smallest-leaf-magnitude guards, then the polar transform of the sign bits
+                const double *src = a + S;
+                const int R = S >= 64 ? S / 64 : 1;
+                const int sft = base & 31;
+                bool zero = false;
+                double q = 1.0;
+                for (int r = 0; r < R; ++r) {
+                    const int j = 64 * r + lane;
+                    const bool in = j < S;
+                    const double v = in ? src[j] : 0.5;
+                    zero |= in && fabs(v) == 1.0;
+                    const double m = fabs(v);
+                    const double t = in ? __builtin_fmax(1.0 - 2.0 * ((m > 1.0) ? 0.0 : m), 0.0) : 1.0;
+                    q = __builtin_fmax(q * t, 1e-300);
+                    const u64 bal = __builtin_amdgcn_ballot_w64(in && ed_is_neg(v));
+                    if (lane == 0) {
+                        if (S >= 64) { bw[(base + 64 * r) >> 5] = (uint32_t)bal; bw[((base + 64 * r) >> 5) + 1] = (uint32_t)(bal >> 32); }
+                        else if (S == 32) bw[base >> 5] = (uint32_t)bal;
+                        else bw[base >> 5] |= ((uint32_t)bal & ((1u << S) - 1u)) << sft;
+                    }
+                }
+                guard |= __builtin_amdgcn_ballot_w64(zero);
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) q = __builtin_fmax(q * __shfl_xor(q, off, 64), 1e-300);
+                if (__builtin_amdgcn_ballot_w64(q < 1e-8)) {
+                    double T = 1.0;                                        // the cheap bound failed: the product itself
+                    for (int r = 0; r < R; ++r) {
+                        const int j = 64 * r + lane;
+                        const bool in = j < S;
+                        const double v = in ? src[j] : 0.5;
+                        const double m = __builtin_fmin(fabs(v), 1.0);
+                        const double t = (in && fabs(v) <= 1.0) ? ed_div(1.0 - m, 1.0 + m) : 1.0;
+                        T = __builtin_fmax(T * t, 1e-300);
+                    }
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) T = __builtin_fmax(T * __shfl_xor(T, off, 64), 1e-300);
+                    guard |= __builtin_amdgcn_ballot_w64(T < 1e-8);
+                }
+                wave_mem_fence();
+                if (S <= 32) {
+                    if (lane == 0) {
+                        const uint32_t m = (S == 32) ? 0xFFFFFFFFu : ((1u << S) - 1u);
+                        const uint32_t x = (bw[base >> 5] >> sft) & m;
+                        uw[base >> 5] |= (uint32_t)bits_transform((u64)x, S) << sft;
+                    }
+                } else {
+                    const int nw = S / 32, w0b = base >> 5;
+                    for (int b0 = lane; b0 < nw; b0 += 64) {
+                        uint32_t x = 0;
+                        for (int b1 = b0; b1 < nw; ++b1) if ((b1 & b0) == b0) x ^= bw[w0b + b1];
+                        uw[w0b + b0] = (uint32_t)bits_transform((u64)x, 32);
+                    }
+                }
+                wave_mem_fence();
+            } else if (type == 4) {
+                // ---- combine: left half ^= right half (child size S)
+                if (S >= 32) {
+                    for (int w = lane; w < S / 32; w += 64) bw[(base >> 5) + w] ^= bw[((base + S) >> 5) + w];
+                } else if (lane == 0) {
+                    const int sft = base & 31;
+                    uint32_t x = bw[base >> 5];
+                    x ^= ((x >> (sft + S)) & ((1u << S) - 1u)) << sft;
+                    bw[base >> 5] = x;
+                }
+                wave_mem_fence();
+            } else if (type == 6) {
+                // ---- all-frozen subtree: the +inf path-metric bound of sc8_decode_kernel (sum of the root's |x| beyond 690)
+                const double *src = a + S;
+                const int R = S >= 64 ? S / 64 : 1;
+                double P = 1.0;
+                bool bad = false;
+                for (int r = 0; r < R; ++r) {
+                    const int j = 64 * r + lane;
+                    const bool in = j < S;
+                    const double m = in ? fabs(src[j]) : 1.0;
+                    bad |= in && m > 1.0;
+                    P *= __builtin_fmin(m, 1.0);
+                    bad |= P < 1e-300;
+                    P = __builtin_fmax(P, 1e-300);
+                }
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    P *= __shfl_xor(P, off, 64);
+                    bad |= P < 1e-300;
+                    P = __builtin_fmax(P, 1e-300);
+                }
+                guard |= __builtin_amdgcn_ballot_w64(bad);
+            }
+        }
+        wave_mem_fence();
+        if (guard != 0 && lane == 0) atomicOr(&p.flag_words[cw >> 5], 1u << (cw & 31));
+        for (int b = lane; b < K; b += 64) {
+            const unsigned pos = p.order[b];
+            p.out[(size_t)cw * K + b] = (uint8_t)((uw[pos >> 5] >> (pos & 31)) & 1u);
+        }
+        wave_mem_fence();
+    }
+}
+size_t polar_sc_lat_lds_bytes(int N) { return 324 * 8 + (size_t)2 * N * 8 + (size_t)2 * ((N + 31) / 32) * 4; }
+int polar_sc_lat_max_log() { return 12; }       // 16 N bytes of LDS per wave: 64 KiB at N = 4096
+hipError_t polar_launch_sc_lat(const PolarScParams &p, int blocks, hipStream_t st) {
+    const size_t lds = polar_sc_lat_lds_bytes(p.N);
+    static bool attr_set = false;
+    if (lds > 48 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sc_lat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sc_lat_kernel, dim3(blocks), dim3(64), lds, st, p);
+    return hipGetLastError();
+}
+
 // flag bit words -> byte flags of the fallback list builder (ed_collect_kernel reads bytes)
 __global__ __launch_bounds__(256) void sc_flags_expand_kernel(const unsigned int *flag_words, uint8_t *flags, long B) {
     for (long cw = (long)blockIdx.x * 256 + threadIdx.x; cw < B; cw += (long)gridDim.x * 256)

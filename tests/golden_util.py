@@ -74,3 +74,16 @@ def sha(a):
 
 def seed():
     return load()[1]["seed"]
+
+
+def both_l1_kernels(g, decode):
+    """List size 1 has two kernels behind one entry point: eight codewords per wave (throughput; batches above 2048) and one
+    codeword per wave with the state in LDS (latency; small batches, N <= 4096). `decode()` is run with each of them forced
+    ("lat_max_b" hook of polar_debug_set) and must return the same bits; returns them."""
+    g.debug_set("lat_max_b", -1)
+    a = decode()
+    g.debug_set("lat_max_b", 1 << 40)
+    b = decode()
+    g.debug_set("lat_max_b", 0)
+    assert (a == b).all(), "the one-codeword-per-wave kernel and the eight-codewords-per-wave kernel disagree"
+    return a

@@ -3,6 +3,8 @@ Bit-exact bar: decoded info bits, encoder output and synthetic LLRs must be iden
 import numpy as np
 import pytest
 
+from golden_util import both_l1_kernels
+
 pytestmark = pytest.mark.gpu
 
 
@@ -46,7 +48,7 @@ def test_decode_scl_llr_matches_oracle(built_lib, oracle_built, n, K, crc, L):
     for ebno in (1.0, 2.0):
         llr, info = o.synth_llr(1234 + L, 0, B, o.snr_sqrt_linear(ebno))
         want = o.decode_scl_llr(llr, L)
-        got = g.decode_scl_llr(llr, L)
+        got = both_l1_kernels(g, lambda: g.decode_scl_llr(llr, L)) if L == 1 else g.decode_scl_llr(llr, L)
         bad = np.nonzero((want != got).any(axis=1))[0]
         assert bad.size == 0, f"{bad.size}/{B} codewords differ (first {bad[:5]}) n={n} K={K} crc={crc} L={L} ebno={ebno}"
 
@@ -262,14 +264,15 @@ def test_list_size_one_unfrozen_leaves_in_the_worst_channels(built_lib, oracle_b
     for ebno in (8.0, 3.0):
         llr, _ = o.synth_llr(77, 0, 1000, o.snr_sqrt_linear(ebno))
         want = o.decode_scl_llr(llr, 1)
-        g.set_mode(0); sc_out = g.decode_scl_llr(llr, 1)
+        g.set_mode(0); sc_out = both_l1_kernels(g, lambda: g.decode_scl_llr(llr, 1))
         g.set_mode(1); gen_out = g.decode_scl_llr(llr, 1)
         # the L = 1 kernel against what the LLR-domain kernel produces: identical, codeword for codeword, at both SNRs
         assert (sc_out == gen_out).all(), (ebno, int((sc_out != gen_out).any(axis=1).sum()))
         gen = int((want != gen_out).any(axis=1).sum())
         print(f"n={n} F={F} Eb/N0={ebno}: LLR-domain kernel vs reference: {gen} differing codewords of 1000")
-        if ebno == 8.0:
-            assert gen == 0
+        # (a loose absolute bound against the reference, so that a drift of the LLR-domain kernel on such codes does not pass
+        # unnoticed behind the kernel-vs-kernel comparison: measured 0 of 1000 at 8 dB on all five codes, 0 ... 1 at 3 dB)
+        assert gen == 0 if ebno == 8.0 else gen <= 4
 
 
 @pytest.mark.parametrize("n,K,crc", [(1, 1, 0), (2, 2, 0), (2, 3, 0), (3, 4, 0), (3, 5, 1), (3, 8, 0), (4, 8, 0), (4, 11, 2), (4, 1, 0)])
@@ -278,7 +281,8 @@ def test_tiny_block_lengths(built_lib, oracle_built, n, K, crc):
     o, g = _pair(n, K, crc)
     llr, _ = o.synth_llr(5, 0, 300, o.snr_sqrt_linear(1.0))
     for L in (1, 2, 4, 8, 32):
-        assert (o.decode_scl_llr(llr, L) == g.decode_scl_llr(llr, L)).all(), L
+        got = both_l1_kernels(g, lambda: g.decode_scl_llr(llr, L)) if L == 1 else g.decode_scl_llr(llr, L)
+        assert (o.decode_scl_llr(llr, L) == got).all(), L
 
 
 @pytest.mark.parametrize("n,K,crc,B", [(13, 4096, 0, 40), (14, 8192, 24, 24), (15, 16384, 0, 11), (12, 3000, 8, 64), (6, 40, 0, 100)])
@@ -287,7 +291,7 @@ def test_list_size_one_long_codes(built_lib, oracle_built, n, K, crc, B):
     conversion kernel), with the deepest fused F-chains, ragged batches (not multiples of the eight codewords per wave)."""
     o, g = _pair(n, K, crc)
     llr, _ = o.synth_llr(707, 0, B, o.snr_sqrt_linear(1.5))
-    assert (o.decode_scl_llr(llr, 1) == g.decode_scl_llr(llr, 1)).all()
+    assert (o.decode_scl_llr(llr, 1) == both_l1_kernels(g, lambda: g.decode_scl_llr(llr, 1))).all()   # (n > 12: both runs take the eight-codeword kernel)
 
 
 @pytest.mark.parametrize("n,K,crc,L,B", [(12, 2048, 16, 8, 24), (13, 4096, 0, 4, 16), (14, 8192, 24, 2, 8),
@@ -317,14 +321,14 @@ def test_list_size_one_reads_the_callers_rows_in_place(built_lib, oracle_built, 
     llr[6, : 1 << (n - 1)] = 800.0               # L-form values through the top G visit
     llr[7] = -llr[7]
     want = o.decode_scl_llr(llr, 1)
-    got = g.decode_scl_llr(llr, 1)
+    got = both_l1_kernels(g, lambda: g.decode_scl_llr(llr, 1))
     g.debug_set("sc_no_fold", 1)
-    got_front = g.decode_scl_llr(llr, 1)
+    got_front = both_l1_kernels(g, lambda: g.decode_scl_llr(llr, 1))
     g.debug_set("sc_no_fold", 0)
     assert (got == want).all() and (got_front == want).all()
     f = llr.astype(np.float32)
     want32 = o.decode_scl_llr(f.astype(np.float64), 1)
-    assert (g.decode_scl_llr(f, 1) == want32).all()
+    assert (both_l1_kernels(g, lambda: g.decode_scl_llr(f, 1)) == want32).all()
 
 
 @pytest.mark.parametrize("n,K,crc,L", [(9, 256, 8, 8), (11, 1024, 16, 32), (6, 20, 3, 1), (11, 1024, 16, 1)])
@@ -338,7 +342,7 @@ def test_float32_llr_boundary(built_lib, oracle_built, n, K, crc, L):
     f = llr.astype(np.float32)
     f[0, :4] = [0.0, -0.0, np.float32(1e-30), np.float32(-3e38)]
     want = o.decode_scl_llr(f.astype(np.float64), L)
-    assert (g.decode_scl_llr(f, L) == want).all()
+    assert ((both_l1_kernels(g, lambda: g.decode_scl_llr(f, L)) if L == 1 else g.decode_scl_llr(f, L)) == want).all()
     d = torch.tensor(f, device="cuda")
     out = torch.empty((B, K), dtype=torch.uint8, device="cuda")
     g.decode_scl_llr_dev_f32(d.data_ptr(), B, L, out.data_ptr())
@@ -380,7 +384,7 @@ def test_degenerate_rows_mixed_with_normal_ones(built_lib, oracle_built, L):
     rows = rng.choice(384, len(special), replace=False)
     for r, s in zip(rows, special):
         llr[r] = s
-    got = g.decode_scl_llr(llr, L)
+    got = both_l1_kernels(g, lambda: g.decode_scl_llr(llr, L)) if L == 1 else g.decode_scl_llr(llr, L)
     bad = [int(r) for r in range(384) if (got[r] != o.decode_scl_llr(llr[r], L)).any()]
     assert not bad, f"rows {bad} differ (special rows: {sorted(int(r) for r in rows)})"
 
@@ -395,7 +399,12 @@ def test_one_codeword_at_a_time_equals_the_batch(built_lib, oracle_built, L):
     batch = g.decode_scl_llr(llr, L)
     assert (batch == o.decode_scl_llr(llr, L)).all()
     for i in range(24):
-        assert (g.decode_scl_llr(llr[i], L) == batch[i]).all(), i
+        assert (g.decode_scl_llr(llr[i], L) == batch[i]).all(), i          # (L = 1: the one-codeword-per-wave kernel, round 4)
+    if L == 1:
+        g.debug_set("lat_max_b", -1)                                       # ... and the eight-codewords-per-wave kernel with B = 1
+        for i in range(24):
+            assert (g.decode_scl_llr(llr[i], L) == batch[i]).all(), i
+        g.debug_set("lat_max_b", 0)
 
 
 def test_reserve_presizes_the_scratch(built_lib, oracle_built):
@@ -453,15 +462,21 @@ def test_list_size_one_accepts_rows_that_are_not_16_byte_aligned(built_lib, orac
         v = buf[off: off + B * 2048]
         v.copy_(torch.from_numpy(llr.reshape(-1)))
         assert v.data_ptr() % 16 == 8 * off
-        g.decode_scl_llr_dev(v.data_ptr(), B, 1, out.data_ptr())
-        torch.cuda.synchronize()
-        assert (out.cpu().numpy() == want).all(), off
+        for lat in (-1, 0):                      # the eight-codeword kernel (in-place reads or front pass), the one-codeword kernel
+            g.debug_set("lat_max_b", lat)
+            out.zero_()
+            g.decode_scl_llr_dev(v.data_ptr(), B, 1, out.data_ptr())
+            torch.cuda.synchronize()
+            assert (out.cpu().numpy() == want).all(), (off, lat)
     f = llr.astype(np.float32)
     want32 = o.decode_scl_llr(f.astype(np.float64), 1)
     buf32 = torch.zeros(B * 2048 + 5, dtype=torch.float32, device="cuda")
     for off in (0, 1, 2, 3):
         v = buf32[off: off + B * 2048]
         v.copy_(torch.from_numpy(f.reshape(-1)))
-        g.decode_scl_llr_dev_f32(v.data_ptr(), B, 1, out.data_ptr())
-        torch.cuda.synchronize()
-        assert (out.cpu().numpy() == want32).all(), off
+        for lat in (-1, 0):
+            g.debug_set("lat_max_b", lat)
+            out.zero_()
+            g.decode_scl_llr_dev_f32(v.data_ptr(), B, 1, out.data_ptr())
+            torch.cuda.synchronize()
+            assert (out.cpu().numpy() == want32).all(), (off, lat)

@@ -31,23 +31,28 @@ for L in (1, 4, 32):
     want = cpu.decode_scl_llr(llr_all[:nc], L)
     cpu_per = (time.perf_counter() - t) / nc
     cross = None
-    for B in (1, 8, 64, 512, 4096):
+    for B in (1, 8, 64, 512, 1024, 2048, 4096):
         llr = np.ascontiguousarray(llr_all[:B])
-        got = g.decode_scl_llr(llr, L)                       # warm-up (allocations) + check
-        m = min(B, nc)
-        assert (got[:m] == want[:m]).all(), (L, B)
-        reps = 30 if B <= 64 else 8
-        ts = []
-        for _ in range(reps):
-            t = time.perf_counter()
-            g.decode_scl_llr(llr, L)
-            ts.append(time.perf_counter() - t)
-        med = float(np.median(ts))
-        r = {"L": L, "B": B, "gpu_call_ms": med * 1e3, "gpu_ms_per_codeword": med * 1e3 / B, "gpu_codewords_per_s": B / med,
-             "cpu_ms_per_codeword_one_core": cpu_per * 1e3, "cpu_kind": kind, "gpu_faster_than_one_core": bool(med / B < cpu_per)}
-        if cross is None and med / B < cpu_per:
-            cross = B
-        rows.append(r); print(r, flush=True)
+        # list size 1 has two kernels (round 4): one codeword per wave (small batches) and eight per wave; "auto" is what a
+        # caller gets, the other two rows force one of them (polar_debug_set "lat_max_b") to show the crossover
+        for variant, knob in ((("auto", 0), ("eight codewords per wave", -1), ("one codeword per wave", 1 << 40)) if L == 1 else (("auto", 0),)):
+            g.debug_set("lat_max_b", knob)
+            got = g.decode_scl_llr(llr, L)                       # warm-up (allocations) + check
+            m = min(B, nc)
+            assert (got[:m] == want[:m]).all(), (L, B)
+            reps = 30 if B <= 64 else 8
+            ts = []
+            for _ in range(reps):
+                t = time.perf_counter()
+                g.decode_scl_llr(llr, L)
+                ts.append(time.perf_counter() - t)
+            med = float(np.median(ts))
+            r = {"L": L, "B": B, "kernel": variant, "gpu_call_ms": med * 1e3, "gpu_ms_per_codeword": med * 1e3 / B, "gpu_codewords_per_s": B / med,
+                 "cpu_ms_per_codeword_one_core": cpu_per * 1e3, "cpu_kind": kind, "gpu_faster_than_one_core": bool(med / B < cpu_per)}
+            if variant == "auto" and cross is None and med / B < cpu_per:
+                cross = B
+            rows.append(r); print(r, flush=True)
+        g.debug_set("lat_max_b", 0)
     rows.append({"L": L, "crossover_batch_vs_one_cpu_core": cross})
 json.dump({"code": "N=2048 K=1024 crc16, Eb/N0 = 2 dB", "abi": "polar_decode_scl_llr_batch (host pointers: H2D + decode + D2H, synchronous)",
            "rows": rows}, open(out_path, "w"), indent=1)
