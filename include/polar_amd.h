@@ -253,6 +253,7 @@ int polar_debug_weak_leaves(const polar_code_t *h);
  * "last_rounds", "last_round_max_per_device", "worker_threads_started" (of the handle's last get_bler_quick* calls). */
 int polar_debug_set(polar_code_t *h, const char *key, long value);
 long polar_debug_get(const polar_code_t *h, const char *key);
+void *polar_debug_scratch_ptr(polar_code_t *h);      /* measurement builds only: where instrumented kernels leave their counters */
 
 #ifdef __cplusplus
 }

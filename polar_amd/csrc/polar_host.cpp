@@ -87,13 +87,14 @@ struct polar_code {
     std::vector<uint32_t> ctl;       // [N] frozen | sched << 1 | weak-unfrozen-leaf << 8
     int weak_leaves = 0;             // unfrozen leaves no construction for an ordinary channel would leave unfrozen (derive_tables)
     std::vector<uint32_t> sc_ops;    // schedule of the list-size-1 kernel (PolarScParams::ops)
+    std::vector<uint32_t> sc_lat_ops;//   the same for its one-codeword-per-wave form: no folded F steps, mixed nodes of size 8 as ONE op (type 7)
     bool sc_fold = false;            //   its top-layer visits read the caller's rows in place (derive_tables)
     // device
     bool dev_ready = false;
     int device = -1, num_cu = 0;
     DevBuf<uint8_t> d_frozen, d_crcm;
     DevBuf<uint16_t> d_order, d_info_rank;
-    DevBuf<uint32_t> d_crc_mask, d_ctl, d_sc_ops, d_var_scr;
+    DevBuf<uint32_t> d_crc_mask, d_ctl, d_sc_ops, d_sc_lat_ops, d_var_scr;
     DevBuf<double> d_tab_scr;
     DevBuf<unsigned int> d_flag_words;
     DevBuf<double> d_llr_scr, d_tabs, d_pre;
@@ -134,6 +135,11 @@ struct polar_code {
     // streams + RCCL communicators of the last multi-device call, kept for the next one with the same device list
     // (an 8-rank ncclCommInitAll costs about as long as a short sweep runs)
     struct MultiCtx *multi = nullptr;
+    // zero-copy staging of the host-pointer entry points for the smallest batches (host_decode): pinned, device-mapped
+    void *pin_in = nullptr, *pin_in_dev = nullptr;     // LLR rows
+    uint8_t *pin_out = nullptr, *pin_out_dev = nullptr; // decoded bits [B][K] followed by one flag byte per codeword
+    size_t pin_in_cap = 0, pin_out_cap = 0;
+    uint8_t *lat_flag_bytes = nullptr;                  // (set around a decode_impl call by host_decode)
     // statistics of the last get_bler_quick* call (polar_debug_get)
     long last_rounds = 0, last_round_max_per_device = 0, worker_threads_started = 0;
     // tuning
@@ -204,6 +210,43 @@ int derive_tables(polar_code *h) {
             }
         } rec{h, emit, N};
         rec.go(0, N);
+        // The one-codeword-per-wave kernel (sc_lat_kernel) decodes a MIXED node of size 8 (neither all frozen nor all
+        // unfrozen) in registers, as one op: type 7, the frozen pattern of its eight leaves in bits 24..31. The ops below
+        // such a node are two thirds of the plain schedule (N = 2048, K = 1024: 1693 ops -> 585), and every op of a lone
+        // wave is a dependent LDS round trip.
+        h->sc_lat_ops.clear();
+        {
+            auto emit2 = [&](int type, int S, int base, uint32_t hi) {
+                int sh = 0; while ((1 << sh) < S) ++sh;
+                h->sc_lat_ops.push_back((uint32_t)type | ((uint32_t)sh << 3) | ((uint32_t)base << 8) | (hi << 24));
+            };
+            struct Rec2 {
+                polar_code *h; decltype(emit2) &em; int N;
+                void go(int lo, int S) {
+                    bool allf = true, nonef = true;
+                    for (int i = lo; i < lo + S; ++i) { if (h->frozen[i]) nonef = false; else allf = false; }
+                    if (allf) { if (S < N) em(6, S, lo, 0u); }
+                    else if (nonef) em(3, S, lo, 0u);
+                    else if (S == 8) {
+                        uint32_t pat = 0;
+                        for (int i = 0; i < 8; ++i) pat |= (uint32_t)(h->frozen[lo + i] ? 1u : 0u) << i;
+                        em(7, S, lo, pat);
+                    } else {
+                        const int hS = S / 2;
+                        em(0, hS, lo, 0u); go(lo, hS);
+                        em(1, hS, lo, 0u); go(lo + hS, hS);
+                        // combine (left half ^= right half): no op of its own — one more step in the combine count of the LAST op
+                        // of the right subtree, the node-completing op the chain starts from (types 3 / 6: bits 24..27, type 7:
+                        // the size field, its size being fixed)
+                        uint32_t &last = h->sc_lat_ops.back();
+                        if ((last & 7u) == 7u) last += 1u << 3;
+                        else last += 1u << 24;
+                    }
+                }
+            } rec2{h, emit2, N};
+            rec2.go(0, N);
+            for (uint32_t &w : h->sc_lat_ops) if ((w & 7u) == 7u) w -= 3u << 3;      // (type 7 was emitted with log2(8) in the count field)
+        }
         // An F or G step followed by the F step of the child it just produced (depth-first order: always the next
         // entry, one size down) takes that F - and one more - along while its results are in registers, as long
         // as the layers involved are HBM-resident (polar_sc8_min_global_log()): bits 24..25 = number of F steps folded in.
@@ -307,6 +350,7 @@ int ensure_device(polar_code *h, DevGuard &dg) {
     if ((rc = upload(h->d_frozen, h->frozen))) return rc;
     if ((rc = upload(h->d_ctl, h->ctl))) return rc;
     if ((rc = upload(h->d_sc_ops, h->sc_ops))) return rc;
+    if ((rc = upload(h->d_sc_lat_ops, h->sc_lat_ops))) return rc;
     if ((rc = upload(h->d_order, h->order))) return rc;
     if ((rc = upload(h->d_info_rank, h->info_rank))) return rc;
     if ((rc = upload(h->d_crc_mask, h->crc_mask))) return rc;
@@ -434,7 +478,9 @@ void polar_destroy(polar_code_t *h) {
     h->d_counter.release(); h->d_sel.release(); h->d_work.release();
     h->d_ech.release(); h->d_flags.release(); h->d_list.release(); h->d_count.release();
     h->d_alive[0].release(); h->d_alive[1].release(); h->d_nalive.release(); h->d_mc_ctr.release();
-    h->d_sc_ops.release(); h->d_flag_words.release(); h->d_var_scr.release(); h->d_tab_scr.release();
+    if (h->pin_in) (void)hipHostFree(h->pin_in);
+    if (h->pin_out) (void)hipHostFree(h->pin_out);
+    h->d_sc_ops.release(); h->d_sc_lat_ops.release(); h->d_flag_words.release(); h->d_var_scr.release(); h->d_tab_scr.release();
     delete h;
 }
 
@@ -494,6 +540,8 @@ int polar_debug_set(polar_code_t *h, const char *key, long value) {
     drop_clones(h);          // (the per-device contexts carry a copy of the knobs)
     return POLAR_OK;
 }
+// (measurement builds: the handle's alpha scratch, where instrumented kernels leave their counters)
+void *polar_debug_scratch_ptr(polar_code_t *h) { return h ? (void *)h->d_llr_scr.p : nullptr; }
 long polar_debug_get(const polar_code_t *h, const char *key) {
     if (!key) return -1;
     const std::string s(key);
@@ -552,8 +600,15 @@ int polar_decode_scl_llr_batch_dev(polar_code_t *h, const double *d_llr, long B,
     return polar_decode_scl_llr_batch_dev_ev(h, d_llr, B, L, d_out, d_pm, stream, nullptr, nullptr);
 }
 
+// list size 1, small batches: one codeword per wave, whole state in LDS (sc_lat_kernel)
+static bool use_sc_lat(const polar_code_t *h, long B) {
+    return h->n <= polar_sc_lat_max_log() && h->knobs.lat_max_b >= 0 && B <= (h->knobs.lat_max_b ? h->knobs.lat_max_b : 2048);
+}
+// phase (list size 1 with the one-codeword-per-wave kernel only): 0 = everything; 1 = the decode kernel alone — the caller
+// looks at the flag words itself and runs phase 2 (work list + general kernel over the flagged codewords) only when one is
+// set; *deferred reports whether phase 1 really left the fallback out
 static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, const unsigned int *n_dev, int L, uint8_t *d_out,
-                       double *d_pm, void *stream, void *ev_start, void *ev_stop);
+                       double *d_pm, void *stream, void *ev_start, void *ev_stop, int phase = 0, int *deferred = nullptr);
 
 int polar_decode_scl_llr_batch_dev_ev(polar_code_t *h, const double *d_llr, long B, int L, uint8_t *d_out,
                                       double *d_pm, void *stream, void *ev_start, void *ev_stop) {
@@ -562,8 +617,9 @@ int polar_decode_scl_llr_batch_dev_ev(polar_code_t *h, const double *d_llr, long
 
 // B rows are allocated; when n_dev != nullptr only the first min(B, *n_dev) exist (count read on the device)
 static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, const unsigned int *n_dev, int L, uint8_t *d_out,
-                       double *d_pm, void *stream, void *ev_start, void *ev_stop) {
+                       double *d_pm, void *stream, void *ev_start, void *ev_stop, int phase, int *deferred) {
     if (!h || !d_llr || !d_out) return fail(POLAR_E_ARG, "NULL argument");
+    if (deferred) *deferred = 0;
     if (L < 1 || L > POLAR_MAX_LIST) return fail(POLAR_E_ARG, "list size %d out of range [1, %d]", L, POLAR_MAX_LIST);
     if (B < 0) return fail(POLAR_E_ARG, "negative batch");
     if (B == 0) return POLAR_OK;
@@ -643,35 +699,40 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
         const bool fold = h->sc_fold && !h->knobs.sc_no_fold && ((uintptr_t)d_llr & 15u) == 0;
         // small batches: one codeword per wave, whole state in LDS (sc_lat_kernel: a lone wave of the eight-codeword kernel pays
         // a memory round trip per dependent access of its HBM-resident layers — B = 1: 0.85 ms against 0.33 ms on a host core)
-        const bool lat = h->n <= polar_sc_lat_max_log() && h->knobs.lat_max_b >= 0 && B <= (h->knobs.lat_max_b ? h->knobs.lat_max_b : 2048);
+        const bool lat = use_sc_lat(h, B);
         if (!fold && !lat && (rc = h->d_ech.ensure((size_t)B * h->N))) return rc;
-        if ((rc = h->d_flags.ensure((size_t)B))) return rc;
         if ((rc = h->d_list.ensure((size_t)B))) return rc;
-        if ((rc = h->d_count.ensure(1))) return rc;
-        if ((rc = h->d_flag_words.ensure((size_t)(B + 31) / 32 + 1))) return rc;
+        // control words and flag words in ONE buffer, zeroed by ONE memset: [0] work counter of the decode kernel, [1] length of
+        // the fallback work list, [2] work counter of the fallback pass, [4 ...] one flag bit per codeword (round 3: four
+        // memsets and two kernels — bits -> bytes -> list — around the decode kernel; a step at batch 65536 is 3.3 ms)
+        const size_t nfw = (size_t)(B + 31) / 32 + 1;
+        if ((rc = h->d_flag_words.ensure(4 + nfw))) return rc;
+        unsigned int *ctrl = h->d_flag_words.p, *fwords = h->d_flag_words.p + 4;
         // (the alpha scratch is shared with the general kernel's, which the fallback pass uses)
         if ((rc = h->d_llr_scr.ensure(std::max((size_t)sgrid * polar_sc8_scratch_doubles_per_wave(h->N) + 64, (size_t)grid * big * 64 + 64)))) return rc;
         p.llr_scr = h->d_llr_scr.p;
-        HIP_TRY(hipMemsetAsync(h->d_flag_words.p, 0, ((size_t)(B + 31) / 32 + 1) * sizeof(unsigned int), st));
-        HIP_TRY(hipMemsetAsync(h->d_count.p, 0, sizeof(unsigned int), st));
-        HIP_TRY(hipMemsetAsync(p.work, 0, sizeof(unsigned int), st));
-        if (!fold && !lat) HIP_TRY(polar_launch_sc8_front(d_llr, llr_f32, h->d_ech.p, h->d_flag_words.p, h->d_tabs.p, h->n, B, n_dev, st));
-        PolarScParams sp;
-        sp.n = h->n; sp.N = h->N; sp.K = h->K; sp.B = B;
-        sp.llr = (fold || lat) ? d_llr : nullptr; sp.llr_f32 = llr_f32;
-        sp.ech_t = (fold || lat) ? nullptr : h->d_ech.p; sp.out = d_out; sp.ops = h->d_sc_ops.p; sp.n_ops = (int)h->sc_ops.size();
-        sp.order = h->d_order.p; sp.tabs = h->d_tabs.p; sp.a_scr = h->d_llr_scr.p;
-        sp.flag_words = h->d_flag_words.p; sp.work = p.work; sp.n_dev = n_dev;
-        if (ev_start) HIP_TRY(hipEventRecord((hipEvent_t)ev_start, st));
-        if (lat) HIP_TRY(polar_launch_sc_lat(sp, (int)std::min<long>(B, (long)h->num_cu * 4), st));
-        else HIP_TRY(polar_launch_sc8_decode(sp, sgrid, st));
-        if (ev_stop) HIP_TRY(hipEventRecord((hipEvent_t)ev_stop, st));
-        HIP_TRY(polar_launch_sc_flags_expand(h->d_flag_words.p, h->d_flags.p, B, st));
-        HIP_TRY(polar_launch_ed_collect(h->d_flags.p, B, n_dev, h->d_list.p, h->d_count.p, st));
-        HIP_TRY(hipMemsetAsync(p.work, 0, sizeof(unsigned int), st));
+        if (phase != 2) {
+            HIP_TRY(hipMemsetAsync(ctrl, 0, (4 + nfw) * sizeof(unsigned int), st));
+            if (!fold && !lat) HIP_TRY(polar_launch_sc8_front(d_llr, llr_f32, h->d_ech.p, fwords, h->d_tabs.p, h->n, B, n_dev, st));
+            PolarScParams sp;
+            sp.n = h->n; sp.N = h->N; sp.K = h->K; sp.B = B;
+            sp.llr = (fold || lat) ? d_llr : nullptr; sp.llr_f32 = llr_f32;
+            sp.ech_t = (fold || lat) ? nullptr : h->d_ech.p; sp.out = d_out; sp.ops = h->d_sc_ops.p; sp.n_ops = (int)h->sc_ops.size();
+            sp.order = h->d_order.p; sp.tabs = h->d_tabs.p; sp.a_scr = h->d_llr_scr.p;
+            sp.flag_words = fwords; sp.work = ctrl; sp.n_dev = n_dev;
+            sp.flag_bytes = lat ? h->lat_flag_bytes : nullptr;
+            if (ev_start) HIP_TRY(hipEventRecord((hipEvent_t)ev_start, st));
+            if (lat) { sp.ops = h->d_sc_lat_ops.p; sp.n_ops = (int)h->sc_lat_ops.size(); }
+            if (lat) HIP_TRY(polar_launch_sc_lat(sp, (int)std::min<long>(B, (long)h->num_cu * 4), st));
+            else HIP_TRY(polar_launch_sc8_decode(sp, sgrid, st));
+            if (ev_stop) HIP_TRY(hipEventRecord((hipEvent_t)ev_stop, st));
+            if (phase == 1 && lat && deferred) { *deferred = 1; return POLAR_OK; }
+        }
+        HIP_TRY(polar_launch_sc_collect(fwords, B, n_dev, h->d_list.p, ctrl + 1, st));
         PolarDecodeParams pf = p;
         pf.prefix_q = 0; pf.prefix_len = 0; pf.pre = nullptr;
-        pf.cw_list = h->d_list.p; pf.cw_count = h->d_count.p; pf.n_dev = nullptr;
+        pf.work = ctrl + 2;
+        pf.cw_list = h->d_list.p; pf.cw_count = ctrl + 1; pf.n_dev = nullptr;
         HIP_TRY(polar_launch_decode_llr(pf, gs, lds_log, pipe, std::min(grid, 16 * wpb), false, st));
         return POLAR_OK;
     }
@@ -717,21 +778,80 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
     return POLAR_OK;
 }
 
-int polar_decode_scl_llr_batch(polar_code_t *h, const double *llr, long B, int L, uint8_t *out) {
+// The host-pointer entry points: H2D copy, decode, wait, copy the bits back. One codeword at a time is the reference's own
+// call pattern (PolarCode.cpp:756, PolarM/main_MC_CC_Comparison.m:96), so the smallest batches of list size 1 are kept to
+// the fewest driver calls: the rows are staged in PINNED, device-mapped host memory that the one-codeword-per-wave kernel
+// reads and writes directly (no DMA copies: a 16-KB hipMemcpy costs more than moving the bytes), the flags come back with
+// the bits, and the work list + general kernel over the flagged codewords (normally none) are launched only when a flag is
+// set — the device-resident entry points, which must not wait, always launch them.
+static int host_decode(polar_code_t *h, const void *llr, int llr_f32, long B, int L, uint8_t *out) {
     if (!h || !llr || !out) return fail(POLAR_E_ARG, "NULL argument");
+    if (L < 1 || L > POLAR_MAX_LIST) return fail(POLAR_E_ARG, "list size %d out of range [1, %d]", L, POLAR_MAX_LIST);
     if (B < 0) return fail(POLAR_E_ARG, "negative batch");
     if (B == 0) return POLAR_OK;
     DevGuard dg_;
     int rc = ensure_device(h, dg_);
     if (rc) return rc;
-    if ((rc = h->d_in.ensure((size_t)B * h->N))) return rc;
-    if ((rc = h->d_out.ensure((size_t)B * h->K))) return rc;
-    HIP_TRY(hipMemcpy(h->d_in.p, llr, (size_t)B * h->N * sizeof(double), hipMemcpyHostToDevice));
-    rc = polar_decode_scl_llr_batch_dev(h, h->d_in.p, B, L, h->d_out.p, nullptr, nullptr);
-    if (rc) return rc;
+    const size_t esz = llr_f32 ? sizeof(float) : sizeof(double);
+    const size_t in_bytes = (size_t)B * h->N * esz, out_bytes = (size_t)B * h->K;
+    const int mode = h->knobs.mode_override >= 0 ? h->knobs.mode_override : h->mode;
+    if (L == 1 && mode != 1 && use_sc_lat(h, B) && B <= 64) {
+        if (h->pin_in_cap < in_bytes) {
+            if (h->pin_in) (void)hipHostFree(h->pin_in);
+            h->pin_in = nullptr; h->pin_in_cap = 0;
+            const size_t cap = std::max(in_bytes, (size_t)64 * h->N * sizeof(double));
+            HIP_TRY(hipHostMalloc(&h->pin_in, cap, hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer(&h->pin_in_dev, h->pin_in, 0));
+            h->pin_in_cap = cap;
+        }
+        if (h->pin_out_cap < out_bytes + (size_t)B) {
+            if (h->pin_out) (void)hipHostFree(h->pin_out);
+            h->pin_out = nullptr; h->pin_out_cap = 0;
+            const size_t cap = (size_t)64 * (h->K + 1);
+            HIP_TRY(hipHostMalloc((void **)&h->pin_out, cap, hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer((void **)&h->pin_out_dev, h->pin_out, 0));
+            h->pin_out_cap = cap;
+        }
+        memcpy(h->pin_in, llr, in_bytes);
+        int deferred = 0;
+        h->lat_flag_bytes = h->pin_out_dev + out_bytes;
+        rc = decode_impl(h, h->pin_in_dev, llr_f32, B, nullptr, L, h->pin_out_dev, nullptr, nullptr, nullptr, nullptr, 1, &deferred);
+        h->lat_flag_bytes = nullptr;
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        bool any = !deferred;
+        for (long i = 0; i < B && !any; ++i) any = h->pin_out[out_bytes + i] != 0;
+        if (any && deferred) {
+            if ((rc = decode_impl(h, h->pin_in_dev, llr_f32, B, nullptr, L, h->pin_out_dev, nullptr, nullptr, nullptr, nullptr, 2, nullptr))) return rc;
+            HIP_TRY(hipStreamSynchronize(nullptr));
+        }
+        memcpy(out, h->pin_out, out_bytes);
+        return POLAR_OK;
+    }
+    void *d_in;
+    if (llr_f32) { if ((rc = h->d_f32.ensure((size_t)B * h->N))) return rc; d_in = h->d_f32.p; }
+    else { if ((rc = h->d_in.ensure((size_t)B * h->N))) return rc; d_in = h->d_in.p; }
+    if ((rc = h->d_out.ensure(out_bytes))) return rc;
+    HIP_TRY(hipMemcpy(d_in, llr, in_bytes, hipMemcpyHostToDevice));
+    int deferred = 0;
+    if ((rc = decode_impl(h, d_in, llr_f32, B, nullptr, L, h->d_out.p, nullptr, nullptr, nullptr, nullptr, 1, &deferred))) return rc;
+    if (deferred) {
+        const size_t nfw = (size_t)(B + 31) / 32;
+        std::vector<unsigned int> fw(nfw);
+        HIP_TRY(hipMemcpy(out, h->d_out.p, out_bytes, hipMemcpyDeviceToHost));          // (waits for the kernel)
+        HIP_TRY(hipMemcpy(fw.data(), h->d_flag_words.p + 4, nfw * sizeof(unsigned int), hipMemcpyDeviceToHost));
+        bool any = false;
+        for (unsigned int w : fw) any |= (w != 0);
+        if (!any) return POLAR_OK;
+        if ((rc = decode_impl(h, d_in, llr_f32, B, nullptr, L, h->d_out.p, nullptr, nullptr, nullptr, nullptr, 2, nullptr))) return rc;
+    }
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, h->d_out.p, (size_t)B * h->K, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, h->d_out.p, out_bytes, hipMemcpyDeviceToHost));
     return POLAR_OK;
+}
+
+int polar_decode_scl_llr_batch(polar_code_t *h, const double *llr, long B, int L, uint8_t *out) {
+    return host_decode(h, llr, 0, B, L, out);
 }
 
 int polar_decode_scl_llr(polar_code_t *h, const double *llr, int L, uint8_t *out) {
@@ -745,20 +865,7 @@ int polar_decode_scl_llr_batch_dev_f32(polar_code_t *h, const float *d_llr, long
     return decode_impl(h, d_llr, 1, B, nullptr, L, d_out, d_pm, stream, nullptr, nullptr);
 }
 int polar_decode_scl_llr_batch_f32(polar_code_t *h, const float *llr, long B, int L, uint8_t *out) {
-    if (!h || !llr || !out) return fail(POLAR_E_ARG, "NULL argument");
-    if (B < 0) return fail(POLAR_E_ARG, "negative batch");
-    if (B == 0) return POLAR_OK;
-    DevGuard dg_;
-    int rc = ensure_device(h, dg_);
-    if (rc) return rc;
-    if ((rc = h->d_f32.ensure((size_t)B * h->N))) return rc;
-    if ((rc = h->d_out.ensure((size_t)B * h->K))) return rc;
-    HIP_TRY(hipMemcpy(h->d_f32.p, llr, (size_t)B * h->N * sizeof(float), hipMemcpyHostToDevice));
-    rc = polar_decode_scl_llr_batch_dev_f32(h, h->d_f32.p, B, L, h->d_out.p, nullptr, nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, h->d_out.p, (size_t)B * h->K, hipMemcpyDeviceToHost));
-    return POLAR_OK;
+    return host_decode(h, llr, 1, B, L, out);
 }
 
 // PolarCode::decode_scl_p1 (PolarCode.cpp:110-128): probability-domain SCL
@@ -1239,7 +1346,7 @@ polar_code *clone_on_device(polar_code *h, int dev, bool fresh = false) {
     c->n = h->n; c->N = h->N; c->K = h->K; c->crc = h->crc; c->eps = h->eps;
     c->frozen = h->frozen; c->order = h->order; c->bitrev = h->bitrev; c->crcm = h->crcm;
     c->W = h->W; c->info_rank = h->info_rank; c->crc_mask = h->crc_mask; c->sched = h->sched; c->ctl = h->ctl;
-    c->sc_ops = h->sc_ops; c->sc_fold = h->sc_fold; c->weak_leaves = h->weak_leaves;
+    c->sc_ops = h->sc_ops; c->sc_lat_ops = h->sc_lat_ops; c->sc_fold = h->sc_fold; c->weak_leaves = h->weak_leaves;
     c->device = dev;
     c->waves_per_cu = h->waves_per_cu; c->lds_log = h->lds_log; c->pipe = h->pipe; c->prefix_on = h->prefix_on; c->mode = h->mode;
     c->knobs = h->knobs;

@@ -71,6 +71,8 @@ struct PolarScParams {
     const double *tabs;          // [322] device
     double *a_scr;               // per-wave scratch: the layers larger than the LDS-resident ones, polar_sc8_scratch_doubles_per_wave()
     unsigned int *flag_words;    // [ceil(B/32)] device, bit = codeword to be decoded again by the general kernel
+    uint8_t *flag_bytes;         // nullptr, or [B] (sc_lat_kernel only): the same flag as a byte per codeword, WRITTEN for every codeword
+                                 //   (the zero-copy host path reads it from pinned memory instead of copying the flag words back)
     unsigned int *work;          // device counter (zeroed before the launch) or nullptr
     const unsigned int *n_dev;   // device: only the first min(B, *n_dev) codewords exist, nullptr = B
 };
@@ -85,10 +87,10 @@ hipError_t polar_launch_sc8_front(const void *llr, int llr_f32, double *ech_p, u
                                   int n, long B, const unsigned *n_dev, hipStream_t st);
 hipError_t polar_launch_sc8_decode(const PolarScParams &p, int grid_waves, hipStream_t st);
 // one codeword per wave, whole state in LDS: the latency form for small batches (N <= 2^polar_sc_lat_max_log())
-size_t polar_sc_lat_lds_bytes(int N);
+size_t polar_sc_lat_lds_bytes(int N, int n_ops);
 int polar_sc_lat_max_log();
 hipError_t polar_launch_sc_lat(const PolarScParams &p, int blocks, hipStream_t st);
-hipError_t polar_launch_sc_flags_expand(const unsigned int *flag_words, uint8_t *flags, long B, hipStream_t st);
+hipError_t polar_launch_sc_collect(const unsigned int *flag_words, long B, const unsigned *n_dev, uint32_t *list, unsigned *count, hipStream_t st);
 
 // Monte-Carlo code construction (polar_construct.hip)
 struct PolarConstructParams {

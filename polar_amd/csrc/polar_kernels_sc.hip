@@ -456,6 +456,69 @@ hipError_t polar_launch_sc8_decode(const PolarScParams &p, int grid_waves, hipSt
 // sc8_decode_kernel's), same guards -> flag word -> the general kernel in the same call. Nodes of size >= 64 are
 // lane-local (j and j + S share a lane); narrower ones read their partner straight from LDS.
 constexpr int SCLAT_U = 4;
+// A whole subtree of S <= 8 leaves decoded in registers (every lane holds the same S root values: one broadcast LDS read
+// instead of an LDS round trip per node of the subtree): frozen pattern `fz` (bit j = leaf j frozen), returns the partial
+// sums of the S leaf positions, `ubits` their decisions. Same arithmetic, pruning identities and guards as the ops of the
+// schedule (types 0, 1, 3, 4, 6 of sc8_decode_kernel), evaluated depth first.
+template <int S>
+__device__ __forceinline__ uint32_t sc_block(const double (&v)[S], uint32_t fz, const Tabs &tb, u64 &guard, uint32_t &ubits) {
+    constexpr uint32_t ALL = (1u << S) - 1u;
+    if (fz == ALL) {                       // all frozen: zeros; the +inf path-metric bound (type 6)
+        double P = 1.0;
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            const double m = fabs(v[j]);
+            bad |= m > 1.0;
+            P *= __builtin_fmin(m, 1.0);
+            bad |= P < 1e-300;
+            P = __builtin_fmax(P, 1e-300);
+        }
+        guard |= __builtin_amdgcn_ballot_w64(bad);
+        ubits = 0u;
+        return 0u;
+    }
+    if (fz == 0u) {                        // all unfrozen: hard decisions of the root, their polar transform (type 3)
+        uint32_t hbits = 0u;
+        bool zero = false;
+        double q = 1.0;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            const double m = fabs(v[j]);
+            zero |= m == 1.0;
+            q = __builtin_fmax(q * __builtin_fmax(1.0 - 2.0 * ((m > 1.0) ? 0.0 : m), 0.0), 1e-300);
+            hbits |= (ed_is_neg(v[j]) ? 1u : 0u) << j;
+        }
+        guard |= __builtin_amdgcn_ballot_w64(zero);
+        if (__builtin_amdgcn_ballot_w64(q < 1e-8)) {
+            double T = 1.0;
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                const double m = __builtin_fmin(fabs(v[j]), 1.0);
+                T = __builtin_fmax(T * ((fabs(v[j]) <= 1.0) ? ed_div(1.0 - m, 1.0 + m) : 1.0), 1e-300);
+            }
+            guard |= __builtin_amdgcn_ballot_w64(T < 1e-8);
+        }
+        ubits = (uint32_t)bits_transform((u64)hbits, S);
+        return hbits;
+    }
+    if constexpr (S > 1) {
+        constexpr int H = S / 2;
+        double l[H], r[H];
+#pragma unroll
+        for (int j = 0; j < H; ++j) l[j] = f_node_e(v[j], v[j + H], guard);
+        uint32_t ul, ur;
+        const uint32_t xl = sc_block<H>(l, fz & ((1u << H) - 1u), tb, guard, ul);
+#pragma unroll
+        for (int j = 0; j < H; ++j) r[j] = g_node_e(v[j], v[j + H], xl << (31 - j), tb);
+        const uint32_t xr = sc_block<H>(r, fz >> H, tb, guard, ur);
+        ubits = ul | (ur << H);
+        return (xl ^ xr) | (xr << H);
+    } else {
+        ubits = 0u;                        // (S = 1 is all frozen or all unfrozen: handled above)
+        return 0u;
+    }
+}
 __global__ __launch_bounds__(64) void sc_lat_kernel(PolarScParams p) {
     const int lane = threadIdx.x;
     const int N = p.N, K = p.K;
@@ -465,14 +528,19 @@ __global__ __launch_bounds__(64) void sc_lat_kernel(PolarScParams p) {
     const int words = (N + 31) / 32;
     uint32_t *bw = reinterpret_cast<uint32_t *>(a + 2 * (size_t)N);   // partial sums, one bit per leaf position
     uint32_t *uw = bw + words;                                        // decisions
+    uint32_t *lops = uw + words;                                      // the schedule, staged once per block: a scalar load per op
+                                                                      // misses the constant cache every 16 ops (~1 us each for a lone wave)
     for (int i = lane; i < 322; i += 64) tabs[i] = p.tabs[i];
+    for (int i = lane; i < p.n_ops; i += 64) lops[i] = p.ops[i];
+    if (lane == 0) lops[p.n_ops] = 0u;
     wave_mem_fence();
     const Tabs tb = {tabs, tabs + 64, tabs + 64 + 129};
     long Bv = p.B;
     if (p.n_dev && (long)*p.n_dev < Bv) Bv = (long)*p.n_dev;
-    typedef const uint32_t __attribute__((address_space(4))) *kconst_u32;
-    const kconst_u32 ops = (kconst_u32)(uintptr_t)p.ops;
     for (long cw = blockIdx.x; cw < Bv; cw += gridDim.x) {
+#ifdef SCLAT_PROF
+        const u64 kstart = __builtin_readcyclecounter();
+#endif
         u64 guard = 0;
         for (int i = lane; i < words; i += 64) { bw[i] = 0u; uw[i] = 0u; }
         {   // channel row -> stored form, kernel element order (element e = channel position bitrev_n(e)); input guard as
@@ -532,11 +600,40 @@ __global__ __launch_bounds__(64) void sc_lat_kernel(PolarScParams p) {
             }
             wave_mem_fence();
         };
-        uint32_t op_next = ops[0];
+#ifdef SCLAT_PROF
+        u64 pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pcnt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        u64 pt0 = __builtin_readcyclecounter();
+        const u64 pstart = pt0;
+#define SCLAT_TICK(k) { const u64 t_ = __builtin_readcyclecounter(); pacc[k] += t_ - pt0; pcnt[k] += 1; pt0 = t_; }
+#else
+#define SCLAT_TICK(k)
+#endif
+        // partial sums of a completed right child (node [b, b + s)) folded into its left sibling, c levels up: the host counts
+        // the combine steps that follow an op instead of scheduling them as ops of their own (a quarter of the schedule)
+        auto combine_chain = [&](int b, int s, int c) {
+            for (; c > 0; --c) {
+                const int lb = b - s;
+                if (s >= 32) {
+                    for (int w = lane; w < s / 32; w += 64) bw[(lb >> 5) + w] ^= bw[(b >> 5) + w];
+                } else if (lane == 0) {
+                    const int sft = lb & 31;
+                    uint32_t x = bw[lb >> 5];
+                    x ^= ((x >> (sft + s)) & ((1u << s) - 1u)) << sft;
+                    bw[lb >> 5] = x;
+                }
+                wave_mem_fence();
+                b = lb; s *= 2;
+            }
+        };
+        uint32_t op_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)lops[0]);
         for (int io = 0; io < p.n_ops; ++io) {
             const uint32_t op = op_next;
-            op_next = ops[io + 1 < p.n_ops ? io + 1 : io];             // (scalar load, one op ahead)
+            const uint32_t opv = lops[io + 1];                           // (LDS, one op ahead; LDS operations return in order:
+                                                                         //  no wait beyond the one the visit's own reads need)
             const int type = (int)(op & 7u), sh = (int)((op >> 3) & 15u), base = (int)((op >> 8) & 0xFFFFu);
+#ifdef SCLAT_PROF
+            const int pk_ = (type <= 1) ? (sh >= 6 ? 8 : type) : type;     // 0 f (S < 64), 1 g (S < 64), 8 f/g (S >= 64), 3, 4, 6, 7
+#endif
             const int extra = (int)((op >> 24) & 3u);                   // F steps of the child chain the host folded into this op
             const int S = 1 << sh;
             if (type <= 1) {
@@ -566,8 +663,12 @@ __global__ __launch_bounds__(64) void sc_lat_kernel(PolarScParams p) {
                     }
                 }
                 guard |= __builtin_amdgcn_ballot_w64(zero);
+                // (every lane's own product >= 0.75 => the product over the 64 lanes >= 0.75^64 > 1e-8: the usual case — the root
+                // values of an all-unfrozen node are large — decided by one compare instead of six cross-lane stages)
+                if (__builtin_amdgcn_ballot_w64(q < 0.75)) {
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) q = __builtin_fmax(q * __shfl_xor(q, off, 64), 1e-300);
+                    for (int off = 1; off < 64; off <<= 1) q = __builtin_fmax(q * __shfl_xor(q, off, 64), 1e-300);
+                }
                 if (__builtin_amdgcn_ballot_w64(q < 1e-8)) {
                     double T = 1.0;                                        // the cheap bound failed: the product itself
                     for (int r = 0; r < R; ++r) {
@@ -598,6 +699,25 @@ __global__ __launch_bounds__(64) void sc_lat_kernel(PolarScParams p) {
                     }
                 }
                 wave_mem_fence();
+                combine_chain(base, S, extra | ((int)((op >> 26) & 3u) << 2));
+            } else if (type == 7) {
+                // ---- mixed node of size 8, decoded in registers (sc_block): its eight root values are one broadcast read
+#ifndef SCLAT_BLOCK_LANES
+#define SCLAT_BLOCK_LANES 64
+#endif
+                if (lane < SCLAT_BLOCK_LANES) {          // (every lane would compute the same thing)
+                    double v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = a[8 + j];
+                    uint32_t ub;
+                    const uint32_t xb = sc_block<8>(v, (op >> 24) & 0xFFu, tb, guard, ub);
+                    if (lane == 0) {
+                        bw[base >> 5] |= xb << (base & 31);
+                        uw[base >> 5] |= ub << (base & 31);
+                    }
+                }
+                wave_mem_fence();
+                combine_chain(base, 8, sh);                              // (type 7: the size is fixed, the field carries the combine count)
             } else if (type == 4) {
                 // ---- combine: left half ^= right half (child size S)
                 if (S >= 32) {
@@ -624,17 +744,34 @@ __global__ __launch_bounds__(64) void sc_lat_kernel(PolarScParams p) {
                     bad |= P < 1e-300;
                     P = __builtin_fmax(P, 1e-300);
                 }
+                // (every lane's own product >= 1e-4 => the product over the 64 lanes >= 1e-256: no cross-lane stage in the usual case)
+                if (__builtin_amdgcn_ballot_w64(P < 1e-4)) {
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    P *= __shfl_xor(P, off, 64);
-                    bad |= P < 1e-300;
-                    P = __builtin_fmax(P, 1e-300);
+                    for (int off = 1; off < 64; off <<= 1) {
+                        P *= __shfl_xor(P, off, 64);
+                        bad |= P < 1e-300;
+                        P = __builtin_fmax(P, 1e-300);
+                    }
                 }
                 guard |= __builtin_amdgcn_ballot_w64(bad);
+                combine_chain(base, S, extra | ((int)((op >> 26) & 3u) << 2));
             }
+            op_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)opv);
+#ifdef SCLAT_PROF
+            SCLAT_TICK(pk_)
+#endif
         }
         wave_mem_fence();
+#ifdef SCLAT_PROF
+        if (lane == 0 && p.a_scr) {
+            u64 *o_ = reinterpret_cast<u64 *>(p.a_scr);
+            for (int k = 0; k < 10; ++k) { atomicAdd(o_ + k, pacc[k]); atomicAdd(o_ + 10 + k, pcnt[k]); }
+            atomicAdd(o_ + 20, pstart - kstart);                              // front pass
+            atomicAdd(o_ + 21, __builtin_readcyclecounter() - kstart);       // everything but the output
+        }
+#endif
         if (guard != 0 && lane == 0) atomicOr(&p.flag_words[cw >> 5], 1u << (cw & 31));
+        if (p.flag_bytes && lane == 0) p.flag_bytes[cw] = (guard != 0) ? 1 : 0;
         for (int b = lane; b < K; b += 64) {
             const unsigned pos = p.order[b];
             p.out[(size_t)cw * K + b] = (uint8_t)((uw[pos >> 5] >> (pos & 31)) & 1u);
@@ -642,10 +779,10 @@ __global__ __launch_bounds__(64) void sc_lat_kernel(PolarScParams p) {
         wave_mem_fence();
     }
 }
-size_t polar_sc_lat_lds_bytes(int N) { return 324 * 8 + (size_t)2 * N * 8 + (size_t)2 * ((N + 31) / 32) * 4; }
+size_t polar_sc_lat_lds_bytes(int N, int n_ops) { return 324 * 8 + (size_t)2 * N * 8 + (size_t)2 * ((N + 31) / 32) * 4 + ((size_t)n_ops + 2) * 4; }
 int polar_sc_lat_max_log() { return 12; }       // 16 N bytes of LDS per wave: 64 KiB at N = 4096
 hipError_t polar_launch_sc_lat(const PolarScParams &p, int blocks, hipStream_t st) {
-    const size_t lds = polar_sc_lat_lds_bytes(p.N);
+    const size_t lds = polar_sc_lat_lds_bytes(p.N, p.n_ops);
     static bool attr_set = false;
     if (lds > 48 * 1024 && !attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sc_lat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -655,15 +792,24 @@ hipError_t polar_launch_sc_lat(const PolarScParams &p, int blocks, hipStream_t s
     return hipGetLastError();
 }
 
-// flag bit words -> byte flags of the fallback list builder (ed_collect_kernel reads bytes)
-__global__ __launch_bounds__(256) void sc_flags_expand_kernel(const unsigned int *flag_words, uint8_t *flags, long B) {
-    for (long cw = (long)blockIdx.x * 256 + threadIdx.x; cw < B; cw += (long)gridDim.x * 256)
-        flags[cw] = (uint8_t)((flag_words[cw >> 5] >> (cw & 31)) & 1u);
+// flag bit words -> work list of the fallback pass (order irrelevant: every codeword is independent)
+__global__ __launch_bounds__(256) void sc_collect_kernel(const unsigned int *flag_words, long B, const unsigned *n_dev, uint32_t *list, unsigned *count) {
+    if (n_dev && (long)*n_dev < B) B = (long)*n_dev;
+    const long nw = (B + 31) / 32;
+    for (long w = (long)blockIdx.x * 256 + threadIdx.x; w < nw; w += (long)gridDim.x * 256) {
+        unsigned int m = flag_words[w];
+        while (m) {
+            const int b = __builtin_ctz(m);
+            m &= m - 1u;
+            const long cw = w * 32 + b;
+            if (cw < B) list[atomicAdd(count, 1u)] = (uint32_t)cw;
+        }
+    }
 }
-
-hipError_t polar_launch_sc_flags_expand(const unsigned int *flag_words, uint8_t *flags, long B, hipStream_t st) {
-    long blocks = (B + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(sc_flags_expand_kernel, dim3((unsigned)blocks), dim3(256), 0, st, flag_words, flags, B);
+hipError_t polar_launch_sc_collect(const unsigned int *flag_words, long B, const unsigned *n_dev, uint32_t *list, unsigned *count, hipStream_t st) {
+    long blocks = ((B + 31) / 32 + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sc_collect_kernel, dim3((unsigned)blocks), dim3(256), 0, st, flag_words, B, n_dev, list, count);
     return hipGetLastError();
 }

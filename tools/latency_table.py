@@ -25,7 +25,7 @@ C.CDLL(None).srand(C.c_uint(1))
 g = polar_amd.PolarCode(n, K, 0.32, crc)
 llr_all, _ = o.synth_llr(99, 0, 4096, o.snr_sqrt_linear(2.0))
 rows = []
-for L in (1, 4, 32):
+for L in [int(x) for x in os.environ.get("LAT_LS", "1,4,32").split(",")]:
     t = time.perf_counter()
     nc = 64 if L == 32 else 512
     want = cpu.decode_scl_llr(llr_all[:nc], L)
