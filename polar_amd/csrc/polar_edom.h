@@ -147,9 +147,24 @@ __device__ __forceinline__ double f_node_e_acc(double a, double b, double &gacc)
     const double q = ed_div(fa + fb, __builtin_fma(fa, fb, 1.0));
     const u64 m_hi = __builtin_amdgcn_fcmp(mn, ED_C40_HI, 2);            // mn > e^-40 (1 + 1e-10): certainly |x| < 40
     const u64 m_l = __builtin_amdgcn_fcmp(mx, 1.0, 2);                   // an L-form input (rare)
+#if !defined(POLAR_NO_GUARD_INT) && !(defined(POLAR_ED_TU) && POLAR_ED_TU == 2)
+    // (A/B, round 4: groups of 4 lanes +0.8 %, groups of 8 +5 %; the list-of-32 translation unit, whose register allocation
+    // every change of the node code shifts, measured -0.45 % with it and keeps the per-node distance below)
+    // Round 4: the distance to the threshold is not tracked at every node (an fp64 add and an fp64 min) but only where it
+    // can matter: every double within 2e-10 (relative) of e^-40 — the whole flagging window, and 2^-20 relative around it —
+    // has the HIGH WORD 0x3C539792, so ONE 32-bit integer compare of the smaller E's high word finds the candidates and the
+    // exact distance is taken in the rare block (shared with the L-form select) only.
+    const u64 m_near = __builtin_amdgcn_uicmp((unsigned)__double2hiint(mn), 0x3C539792u, 32);     // ICMP_EQ
+    double r = __builtin_amdgcn_inverse_ballot_w64(m_hi) ? q : mx;
+    if (POLAR_UNLIKELY((m_l | m_near) != 0)) {
+        r = __builtin_amdgcn_inverse_ballot_w64(m_l) ? mn : r;
+        gacc = ed_absmin(gacc, mn - ED_C40_HI);
+    }
+#else
     gacc = ed_absmin(gacc, mn - ED_C40_HI);
     double r = __builtin_amdgcn_inverse_ballot_w64(m_hi) ? q : mx;
     if (POLAR_UNLIKELY(m_l != 0)) r = __builtin_amdgcn_inverse_ballot_w64(m_l) ? mn : r;
+#endif
     return ed_with_sign(r, __double2hiint(a) ^ __double2hiint(b));
 }
 constexpr double ED_GACC_FLAG = 4.248354255291589e-18 * 2.0000001e-10;      // flagged: |mn - e^-40 (1 + 1e-10)| <= this

@@ -5,7 +5,7 @@ REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 for T in "$@"; do
   rm -rf /tmp/ic_$T
-  POLAR_AMD_LIB=$REPO/polar_amd/libpolar_amd_$T.so rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d /tmp/ic_$T -o pmc --output-format csv -- python $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-other-configs > /tmp/ic_$T.log 2>&1
+  POLAR_AMD_LIB=$REPO/polar_amd/libpolar_amd_$T.so rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d /tmp/ic_$T -o pmc --output-format csv -- python $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-other-configs --mc-trials 0 > /tmp/ic_$T.log 2>&1
   python - "$T" <<'PY'
 import csv, glob, collections, sys
 T = sys.argv[1]

@@ -6,8 +6,8 @@ T=${1:-r03}; O=gpurun_out/$T; mkdir -p $O
 sha256sum polar_amd/libpolar_amd.so > $O/lib_sha256.txt
 (timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3) > $O/gpu_tests.txt
 python bench.py > $O/bench.json 2> $O/bench.err
-python bench.py --batch 524288 --cpu-sample 0 --no-other-configs > $O/bench_b524288.json 2>> $O/bench.err
-bash tools/profile.sh ${T} --steps 2 --warmup 1 --no-other-configs > /dev/null 2>&1
+python bench.py --batch 524288 --cpu-sample 0 --no-other-configs --mc-trials 0 > $O/bench_b524288.json 2>> $O/bench.err
+bash tools/profile.sh ${T} --steps 2 --warmup 1 --no-other-configs --mc-trials 0 > /dev/null 2>&1
 bash tools/profile_configs.sh config1 config2 config2_b262144 config3 config5 > $O/profile_configs.log 2>&1
 rm -rf gpurun_out/ic1 gpurun_out/ic2; bash tools/icache_pmc.sh 2>&1 | tail -2 > $O/icache_pmc.txt
 mkdir -p gpurun_out/st_$T; bash tools/stall_pmc.sh $T 2>&1 | tail -4 > $O/stall_pmc.txt
@@ -20,4 +20,6 @@ python tools/fuzz_parity.py 150 12 > $O/fuzz_any.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 tools/mall_microbench.hip -o /tmp/mb 2>/dev/null && /tmp/mb > $O/cache_footprint_microbench.txt
 python tools/mc_rate.py 32 1048576 > $O/mc_rate.txt 2>&1
 python tools/sc_rounds.py $O/sc_rounds.json > $O/sc_rounds.txt 2>&1
+python tools/config4_record.py 100 8388608 > $O/config4_record.json 2>> $O/bench.err
+python tools/fuzz_parity_p1.py 60 > $O/fuzz_p1.txt 2>&1
 cat $O/gpu_tests.txt; tail -c 400 $O/bench_b524288.json; tail -2 $O/stress_parity.txt $O/fuzz_sane.txt $O/fuzz_any.txt $O/mc_rate.txt
