@@ -740,6 +740,38 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
     // (round 3: automatic mode takes the exp-domain kernel from lists of 3 on — it was 5: with the block-placement hints the
     // 4-lane groups run 16 % faster on it, config 3: 4.4 -> 5.1 M cw/s)
     const bool ed = ((mode == 2) || (mode == 0 && gs >= 4)) && gs >= 4;
+    // Small batches of the small lists: ONE codeword per wave, its elements spread over the 64 / gs lanes of each path, the state in
+    // LDS (scl_decode_llr_kernel<.., LAT = 1>; exp-domain arithmetic for groups of 4 and 8 lanes, LLR-domain for groups of 2). The
+    // kernel converts the channel itself (no conversion pass, no prefix kernel).
+    const bool lat_list = (gs == 2 ? !ed : (ed && (gs == 4 || gs == 8))) && h->knobs.lat_max_b >= 0 &&
+                          B <= (h->knobs.lat_max_b ? h->knobs.lat_max_b : 96) && polar_decode_lat_lds_bytes(h->N, gs, h->W) <= (size_t)160 * 1024;
+    if (lat_list) {
+        PolarDecodeParams pl = p;
+        pl.prefix_q = 0; pl.prefix_len = 0; pl.pre = nullptr;
+        const int blocks = (int)std::min<long>(B, (long)h->num_cu);
+        if (ed) {
+            if ((rc = h->d_flags.ensure((size_t)B))) return rc;
+            if ((rc = h->d_list.ensure((size_t)B))) return rc;
+            if ((rc = h->d_count.ensure(1))) return rc;
+            pl.flags = h->d_flags.p;
+        }
+        if (phase != 2) {
+            HIP_TRY(hipMemsetAsync(p.work, 0, sizeof(unsigned int), st));
+            if (ev_start) HIP_TRY(hipEventRecord((hipEvent_t)ev_start, st));
+            HIP_TRY(polar_launch_decode_lat(pl, gs, ed, blocks, st));
+            if (ev_stop) HIP_TRY(hipEventRecord((hipEvent_t)ev_stop, st));
+            if (!ed) return POLAR_OK;
+            if (phase == 1 && deferred) { *deferred = 2; return POLAR_OK; }        // (flag BYTES in d_flags: the caller looks)
+        } else if (!ed) return POLAR_OK;
+        HIP_TRY(hipMemsetAsync(h->d_count.p, 0, sizeof(unsigned int), st));
+        HIP_TRY(polar_launch_ed_collect(h->d_flags.p, B, n_dev, h->d_list.p, h->d_count.p, st));
+        HIP_TRY(hipMemsetAsync(p.work, 0, sizeof(unsigned int), st));
+        PolarDecodeParams pf = p;
+        pf.prefix_q = 0; pf.prefix_len = 0; pf.pre = nullptr;
+        pf.cw_list = h->d_list.p; pf.cw_count = h->d_count.p; pf.n_dev = nullptr;
+        HIP_TRY(polar_launch_decode_llr(pf, gs, lds_log, pipe, std::min(grid, 64 * wpb), false, st));
+        return POLAR_OK;
+    }
     HIP_TRY(hipMemsetAsync(p.work, 0, sizeof(unsigned int), st));
     if (!ed) {
         if (p.prefix_q) HIP_TRY(polar_launch_prefix(p, false, st));
@@ -836,12 +868,18 @@ static int host_decode(polar_code_t *h, const void *llr, int llr_f32, long B, in
     int deferred = 0;
     if ((rc = decode_impl(h, d_in, llr_f32, B, nullptr, L, h->d_out.p, nullptr, nullptr, nullptr, nullptr, 1, &deferred))) return rc;
     if (deferred) {
-        const size_t nfw = (size_t)(B + 31) / 32;
-        std::vector<unsigned int> fw(nfw);
         HIP_TRY(hipMemcpy(out, h->d_out.p, out_bytes, hipMemcpyDeviceToHost));          // (waits for the kernel)
-        HIP_TRY(hipMemcpy(fw.data(), h->d_flag_words.p + 4, nfw * sizeof(unsigned int), hipMemcpyDeviceToHost));
         bool any = false;
-        for (unsigned int w : fw) any |= (w != 0);
+        if (deferred == 1) {                 // list size 1: flag words
+            const size_t nfw = (size_t)(B + 31) / 32;
+            std::vector<unsigned int> fw(nfw);
+            HIP_TRY(hipMemcpy(fw.data(), h->d_flag_words.p + 4, nfw * sizeof(unsigned int), hipMemcpyDeviceToHost));
+            for (unsigned int w : fw) any |= (w != 0);
+        } else {                             // small lists: flag bytes
+            std::vector<uint8_t> fb((size_t)B);
+            HIP_TRY(hipMemcpy(fb.data(), h->d_flags.p, (size_t)B, hipMemcpyDeviceToHost));
+            for (uint8_t b : fb) any |= (b != 0);
+        }
         if (!any) return POLAR_OK;
         if ((rc = decode_impl(h, d_in, llr_f32, B, nullptr, L, h->d_out.p, nullptr, nullptr, nullptr, nullptr, 2, nullptr))) return rc;
     }

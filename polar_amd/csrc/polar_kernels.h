@@ -40,6 +40,9 @@ hipError_t polar_launch_prefix_ed0(const PolarDecodeParams &p, hipStream_t st);
 hipError_t polar_launch_prefix_ed1(const PolarDecodeParams &p, hipStream_t st);
 hipError_t polar_launch_decode_llr_ed0(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, hipStream_t st);
 hipError_t polar_launch_decode_llr_ed1(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, hipStream_t st);
+// one codeword per wave, state in LDS (the latency form; list sizes 2 .. 8 while polar_decode_lat_lds_bytes() fits 160 KiB)
+hipError_t polar_launch_decode_lat(const PolarDecodeParams &p, int gs, bool ed, int blocks, hipStream_t st);
+size_t polar_decode_lat_lds_bytes(int N, int gs, int W);
 hipError_t polar_launch_decode_llr(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, bool ed, hipStream_t st);
 hipError_t polar_launch_ed_front(const void *llr, int llr_f32, double *ech, uint8_t *flags, const double *tabs, int N, long B, const unsigned *n_dev, hipStream_t st);
 hipError_t polar_launch_ed_collect(const uint8_t *flags, long B, const unsigned *n_dev, uint32_t *list, unsigned *count, hipStream_t st);

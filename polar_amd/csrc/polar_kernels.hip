@@ -247,14 +247,22 @@ __device__ __forceinline__ const double *ch_row(const PolarDecodeParams &p, size
     (void)lig; (void)gbase;
 // NL: 0 = block length taken from p (any code); else log2 of the block length this instantiation is compiled for (the
 // headline shapes: every layer size, row offset and loop bound is then a constant)
-template <int GS, int LDS_LOG, int PIPE, bool ED, int NL = 0>
+// LAT = 1: the LATENCY form for small batches (round 4) — ONE codeword per wave. The 64 / GS lane groups that otherwise hold
+// different codewords share the ELEMENTS of one codeword: lane = e * GS + l decodes path l and owns the elements j = e (mod 64 / GS) of
+// every layer. Everything a path carries (metric, slot pointers, partial sums, history) is replicated in its 64 / GS lanes, which
+// execute the leaf steps — fork, prune, clone, CRC, selection: the code below, unchanged — in lockstep with identical operands; only
+// the layer visits differ (lat_visit), and the whole state lives in LDS: layers (N - 1) GS doubles (element j of slot s at
+// [(j GS + s)]: a wave access is 64 consecutive doubles), the converted channel, the partial-sum and history words. A lone wave of the
+// batch kernel pays an HBM round trip per dependent access of its scratch layers and evaluates every element of a layer serially.
+template <int GS, int LDS_LOG, int PIPE, bool ED, int NL = 0, int LAT = 0>
 __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_llr_kernel(PolarDecodeParams p) {
     // ED: exp-domain node arithmetic (see f_node_e); the channel values at p.llr are then in stored form
     // (ed_front_kernel) and every codeword whose decisions are not safely reproduced is reported in p.flags
     // PIPE=1: one wave per block (8 waves/CU, register double-buffering); PIPE=0: four independent
     // waves per block sharing the transcendental tables (16 waves/CU with LDS_LOG = 3)
     constexpr int WPB = PIPE ? 1 : 4;
-    constexpr int G = 64 / GS;
+    constexpr int G = LAT ? 1 : 64 / GS;           // codewords per wave
+    constexpr int EL = 64 / GS;                    // (LAT) lanes that share the elements of a path's layers
     constexpr int SL = 1 << LDS_LOG;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave in block (uniform: keeps every per-wave base pointer in SGPRs)
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     const int nwaves = gridDim.x * WPB;
     const int lig = lane & (GS - 1);   // path index l of the reference
     const int gbase = lane & ~(GS - 1);
-    const int grp = lane / GS;
+    const int grp = LAT ? 0 : lane / GS;
     const int n = NL ? NL : p.n, N = NL ? (1 << NL) : p.N, K = p.K, L = p.L;
     const u64 gmask = (GS == 64) ? ~0ull : ((1ull << GS) - 1ull);
 
@@ -297,13 +305,16 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     // (fallback pass: codewords come from p.cw_list; Monte-Carlo: only the first *p.n_dev rows are alive)
     const long Bv = p.cw_count ? (long)*p.cw_count : (p.n_dev ? ((long)*p.n_dev < p.B ? (long)*p.n_dev : p.B) : p.B);
 
-    // per-wave global scratch
+    // per-wave global scratch (LAT: the same arrays in LDS, behind the wave's other LDS data)
     const size_t big_elems = (N > 2 * SL) ? (size_t)(N - 2 * SL) : 0;
-    double *g_llr = p.llr_scr + (size_t)wave_id * big_elems * 64;
+    double *g_llr = LAT ? nullptr : p.llr_scr + (size_t)wave_id * big_elems * 64;
     const int cwords = (N >= 128) ? (N / 32 - 2) : 0;                          // words of big C layers (S >= 64)
-    uint32_t *g_cl = p.c_scr + (size_t)wave_id * 2 * (size_t)cwords * 64;
+    double *lat_ch = reinterpret_cast<double *>(stackv + 128);                  // (LAT) [N] channel, stored form, kernel element order
+    double *lat_a = lat_ch + N;                                                // (LAT) layers: size S at (S - 1) GS, element j of slot s at (j GS + s)
+    uint32_t *lat_w = reinterpret_cast<uint32_t *>(lat_a + (size_t)N * GS);
+    uint32_t *g_cl = LAT ? lat_w : p.c_scr + (size_t)wave_id * 2 * (size_t)cwords * 64;
     uint32_t *g_cr = g_cl + (size_t)cwords * 64;
-    uint32_t *g_hist = p.hist_scr + (size_t)wave_id * 3 * (size_t)p.W * 64;    // decision words [W][64]
+    uint32_t *g_hist = LAT ? g_cr + (size_t)cwords * 64 : p.hist_scr + (size_t)wave_id * 3 * (size_t)p.W * 64;    // decision words [W][64]
     uint32_t *g_horg = g_hist + (size_t)p.W * 64;                              // link to the previous word's slot
     uint32_t *g_tb = g_horg + (size_t)p.W * 64;                                // winner's words, per-lane copy
     // ---- table mode (list size 17..32, N >= 1024, exp-domain): layers 1 and 2 are never stored per path.
@@ -330,7 +341,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         gacc = __builtin_inf();
 #endif
         auto cw_of_lane = [&](int ln) -> size_t {
-            const long i = g0 + ln / GS;
+            const long i = g0 + (LAT ? 0 : ln / GS);
             return p.cw_list ? (size_t)p.cw_list[i < Bv ? i : Bv - 1] : (size_t)i;     // (lanes past the end of the work list: any valid row)
         };
         auto FN2 = [&](double a0_, double b0_, double a1_, double b1_, double &r0_, double &r1_) {
@@ -355,6 +366,28 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         uint32_t hword = 0;                        // decisions of the current 32 unfrozen steps
         int origin = lig;                          // slot that holds this path's flushed history
         unsigned t = 0;                            // unfrozen steps so far (wave-uniform)
+        if constexpr (LAT) {
+            // channel row -> stored form (or the plain LLRs for the LLR-domain arithmetic), kernel element order: element e is channel
+            // position bitrev_n(e), so that the pair (2b, 2b + 1) the top layer combines sits at (j, j + N/2); input guard of ed_front_kernel
+            bool any = false, sized = false;
+            const size_t row = (size_t)(valid ? cw : 0) * (size_t)N;
+            for (int i0 = 0; i0 < N; i0 += 64 * 8) {
+                double x[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = i0 + 64 * k + lane;
+                    x[k] = (i < N) ? (p.llr_f32 ? (double)reinterpret_cast<const float *>(p.llr)[row + i] : p.llr[row + i]) : 1.0;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = i0 + 64 * k + lane;
+                    double v = x[k];
+                    if constexpr (ED) { bool f; v = ed_from_channel(x[k], tb, f); any |= f; sized |= fabs(x[k]) >= 0.1; }
+                    if (i < N) lat_ch[__brev((unsigned)i) >> (32 - n)] = v;
+                }
+            }
+            if constexpr (ED) { if (wave_any(any) || !wave_any(sized)) guard = ~0ull; }
+        }
         wave_mem_fence();
 
         // ================= all-frozen prefix (computed by prefix_kernel) =================
@@ -461,6 +494,46 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
             const int lam_top = (phi == phi_start && forced_top) ? forced_top : (phi ? (n - __builtin_ctz((unsigned)phi)) : 1);
             double leaf = 0.0;
             for (int lam = lam_top; lam <= lam_stop; ++lam) {
+                if constexpr (LAT) {
+                    // ---- one layer, its elements spread over the 64 / GS lanes of each path (see the template's comment)
+                    LANE_CTX
+                    const int sh_ = n - lam, S_ = 1 << sh_, e_ = lane / GS;
+                    const bool odd_ = (phi >> sh_) & 1;
+                    const int pin_ = (lam > 1) ? pL.get(sh_ + 1) : 0;
+                    const double *srcp = (lam > 1) ? lat_a + (size_t)(2 * S_ - 1) * GS + pin_ : lat_ch;
+                    const int sstr = (lam > 1) ? GS : 1;
+                    double *dstp = lat_a + (size_t)(S_ - 1) * GS + lig;
+                    const uint32_t *cwp_ = (odd_ && S_ > 32) ? g_cl + (size_t)(S_ / 32 - 2) * 64 + gbase + pC.get(sh_) : nullptr;
+                    auto one = [&](int j, double a_, double b_) -> double {
+                        if (!odd_) return FN(a_, b_);
+                        if (S_ <= 32) return GN(a_, b_, (uint32_t)(clsmall >> S_), j);
+                        return GN(a_, b_, cwp_[(size_t)(j >> 5) * 64], j & 31);
+                    };
+                    if (S_ >= 4 * EL) {
+                        for (int j0 = e_; j0 < S_; j0 += 4 * EL) {
+                            double a_[4], b_[4], r_[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) { a_[k] = srcp[(size_t)(j0 + k * EL) * sstr]; b_[k] = srcp[(size_t)(j0 + k * EL + S_) * sstr]; }
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) r_[k] = one(j0 + k * EL, a_[k], b_[k]);
+                            if (active) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) dstp[(size_t)(j0 + k * EL) * GS] = r_[k];
+                            }
+                        }
+                    } else {
+                        for (int j = e_; j < (S_ > EL ? S_ : EL); j += EL) {
+                            const bool in_ = j < S_;
+                            const double a_ = srcp[(size_t)(in_ ? j : 0) * sstr], b_ = srcp[(size_t)((in_ ? j : 0) + S_) * sstr];
+                            const double r_ = one(in_ ? j : 0, a_, b_);
+                            if (active && in_) dstp[(size_t)j * GS] = r_;
+                        }
+                    }
+                    if (active) pL.set(sh_, lig);
+                    wave_mem_fence();
+                    if (S_ == 1) leaf = lat_a[lig];            // (every lane of the path: the element-0 lane wrote it)
+                    continue;
+                }
                 if (POLAR_UNLIKELY2(tbl && lam <= 2 && phi >= S2)) {
                     // phi = N/4, N/2, 3N/4: the visits of layers 1 and 2 are replaced by the table build
                     const int kind = phi / S2;                      // 1: h (g of the shared layer 1), 2: f, 3: g
@@ -974,13 +1047,14 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 };
                 // (one instantiation per address space of the source: a maybe-LDS-maybe-global pointer would
                 // turn the loads into FLAT instructions that wait for every outstanding memory operation)
-                auto rate0 = [&](const double *yp) {
+                auto rate0 = [&](const double *yp, auto STR_) {
+                    constexpr int YS = decltype(STR_)::value;         // distance between the elements of the layer (LAT: GS)
                     if (zb == 3) {
                         double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
                         if (active) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                const double lo = yp[(size_t)j * 64], hi = yp[(size_t)(j + 4) * 64];
+                                const double lo = yp[(size_t)j * YS], hi = yp[(size_t)(j + 4) * YS];
                                 a[j] = FN(lo, hi);
                                 b[j] = GN(lo, hi, 0u, 0);
                             }
@@ -991,13 +1065,14 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                         double y[4] = {0, 0, 0, 0};
                         if (active) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) y[j] = yp[(size_t)j * 64];
+                            for (int j = 0; j < 4; ++j) y[j] = yp[(size_t)j * YS];
                         }
                         block4(y[0], y[1], y[2], y[3]);
                     }
                 };
-                if (Z <= SL) rate0(lds_llr + (size_t)(Z - 1) * 64 + lane);
-                else rate0(g_llr + (size_t)(Z - 2 * SL) * 64 + lane);
+                if constexpr (LAT) rate0(lat_a + (size_t)(Z - 1) * GS + lig, std::integral_constant<int, GS>{});
+                else if (Z <= SL) rate0(lds_llr + (size_t)(Z - 1) * 64 + lane, std::integral_constant<int, 64>{});
+                else rate0(g_llr + (size_t)(Z - 2 * SL) * 64 + lane, std::integral_constant<int, 64>{});
                 const int nu = phi >> zb;                     // node index of the block at its layer
                 if ((nu & 1) == 0) {
                     if (active) clsmall &= ~((((u64)1 << Z) - 1ull) << Z);   // column 0 of that layer := 0
@@ -1417,7 +1492,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
             wave_mem_fence();
         }
         if (valid) {
-            for (int b = lig; b < K; b += GS) {
+            for (int b = LAT ? lane : lig; b < K; b += LAT ? 64 : GS) {
                 unsigned r = p.info_rank[b];
                 uint32_t wd = g_tb[(size_t)(r >> 5) * 64 + lane];
                 p.out[(size_t)cw * K + b] = win_active ? (uint8_t)((wd >> (r & 31)) & 1u) : (uint8_t)0;
@@ -1428,7 +1503,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
 #ifndef POLAR_NO_GMIN
             guard |= __ballot(gacc <= ED_GACC_FLAG);
 #endif
-            if (valid && lig == 0 && ((guard >> gbase) & gmask) != 0) p.flags[cw] = 1;
+            if constexpr (LAT) { if (valid && lane == 0) p.flags[cw] = (guard != 0) ? 1 : 0; }      // (no conversion pass has cleared it)
+            else if (valid && lig == 0 && ((guard >> gbase) & gmask) != 0) p.flags[cw] = 1;
         }
         wave_mem_fence();
 #ifdef POLAR_MARGIN
@@ -1724,6 +1800,41 @@ static hipError_t launch_gs(const PolarDecodeParams &p, int lds_log, int pipe, i
 #undef POLAR_LAUNCH
     return hipGetLastError();
 }
+
+// LAT instantiations (one codeword per wave, state in LDS): exp-domain arithmetic for the groups of 4 and 8 lanes (this
+// file compiled with POLAR_ED_TU = 1), LLR-domain for the groups of 2 (POLAR_ED_TU = 0)
+template <int GS, bool ED>
+static hipError_t launch_lat(const PolarDecodeParams &p, int blocks, hipStream_t st) {
+    const int cwords = (p.N >= 128) ? (p.N / 32 - 2) : 0;
+    const size_t lds = polar_decode_lds_bytes(3, 1) + (size_t)p.N * 8 + (size_t)p.N * GS * 8 + ((size_t)2 * cwords + (size_t)3 * p.W) * 64 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&scl_decode_llr_kernel<GS, 3, 1, ED, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((scl_decode_llr_kernel<GS, 3, 1, ED, 0, 1>), dim3(blocks), dim3(64), lds, st, p);
+    return hipGetLastError();
+}
+#if POLAR_ED_TU == 1
+hipError_t polar_launch_decode_lat_ed1(const PolarDecodeParams &p, int gs, int blocks, hipStream_t st) {
+    switch (gs) {
+        case 4: return launch_lat<4, true>(p, blocks, st);
+        case 8: return launch_lat<8, true>(p, blocks, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+#elif POLAR_ED_TU == 0
+hipError_t polar_launch_decode_lat_ed1(const PolarDecodeParams &p, int gs, int blocks, hipStream_t st);
+hipError_t polar_launch_decode_lat(const PolarDecodeParams &p, int gs, bool ed, int blocks, hipStream_t st) {
+    if (ed) return polar_launch_decode_lat_ed1(p, gs, blocks, st);
+    if (gs == 2) return launch_lat<2, false>(p, blocks, st);
+    return hipErrorInvalidValue;
+}
+size_t polar_decode_lat_lds_bytes(int N, int gs, int W) {
+    const int cwords = (N >= 128) ? (N / 32 - 2) : 0;
+    return polar_decode_lds_bytes(3, 1) + (size_t)N * 8 + (size_t)N * gs * 8 + ((size_t)2 * cwords + (size_t)3 * W) * 64 * 4;
+}
+#endif
 
 #if POLAR_ED_TU == 2
 hipError_t polar_launch_decode_llr_ed1_gs32(const PolarDecodeParams &p, int lds_log, int pipe, int grid, hipStream_t st) {

@@ -76,14 +76,19 @@ def seed():
     return load()[1]["seed"]
 
 
-def both_l1_kernels(g, decode):
-    """List size 1 has two kernels behind one entry point: eight codewords per wave (throughput; batches above 2048) and one
-    codeword per wave with the state in LDS (latency; small batches, N <= 4096). `decode()` is run with each of them forced
-    ("lat_max_b" hook of polar_debug_set) and must return the same bits; returns them."""
+def both_kernels(g, decode):
+    """The list sizes 1 ... 8 have two kernels behind one entry point: the batch kernels (many codewords per wave, the big layers
+    in an HBM scratch: throughput) and the latency kernels (ONE codeword per wave, its elements spread over the lanes, the state in
+    LDS: list size 1 up to 2048 codewords and N <= 4096, list sizes 2 ... 8 up to 96 codewords while the state fits the LDS).
+    `decode()` is run with each of them forced ("lat_max_b" hook of polar_debug_set: -1 = never, a huge value = whenever the
+    shape allows) and must return the same bits; returns them."""
     g.debug_set("lat_max_b", -1)
     a = decode()
     g.debug_set("lat_max_b", 1 << 40)
     b = decode()
     g.debug_set("lat_max_b", 0)
-    assert (a == b).all(), "the one-codeword-per-wave kernel and the eight-codewords-per-wave kernel disagree"
+    assert (a == b).all(), "the one-codeword-per-wave kernel and the batch kernel disagree"
     return a
+
+
+both_l1_kernels = both_kernels

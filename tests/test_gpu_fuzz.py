@@ -93,3 +93,72 @@ def test_rows_with_a_tiny_channel_take_the_llr_domain_kernel(built_lib, oracle_b
     print(f"n={n} K={K} L={L}: rows differing from the reference — LLR-domain {d_llr}, automatic {d_auto} (of {B}, half of them x 1e-3)")
     assert d_auto <= d_llr
     assert (want[~tiny] == b[~tiny]).all() and (want[~tiny] == a[~tiny]).all()   # ordinary rows: the reference's bits
+
+
+def test_fuzz_slice_latency_kernels(built_lib, oracle_built):
+    """The one-codeword-per-wave kernels (round 4: list size 1 with the state in LDS; list sizes 2 ... 8 with the elements of
+    every layer spread over the lanes of a path) on 80 random configurations a construction produces — block lengths 8 ... 4096,
+    list sizes 1 ... 8 incl. 3, 5, 6, 7, CRCs, -1 ... 4.5 dB, degenerate rows mixed in — forced on whatever the batch size
+    ("lat_max_b"), against the oracle AND against the batch kernels: zero mismatching ordinary rows."""
+    import ctypes as C
+    import polar_amd
+    from oracle_lib import Oracle
+    rng = np.random.default_rng(4242)
+    total = bad = used_lat = 0
+    fails = []
+    for it in range(80):
+        cfg = fuzz_util.draw(rng, sane=True)
+        cfg["L"] = int(rng.choice([1, 2, 3, 4, 4, 5, 6, 7, 8, 8]))
+        n, N, K, crc, L = cfg["n"], cfg["N"], cfg["K"], cfg["crc"], cfg["L"]
+        B = int(rng.choice([1, 3, 17, 40]))
+        o = Oracle(n, K, cfg["eps"], crc, srand=it + 1)
+        C.CDLL(None).srand(C.c_uint(it + 1))
+        g = polar_amd.PolarCode(n, K, cfg["eps"], crc)
+        llr, _ = o.synth_llr(3000 + it, 0, B, o.snr_sqrt_linear(cfg["ebno"]))
+        deg = B >= 17 and rng.random() < 0.3
+        if deg:                                                    # the three degenerate rows of tools/fuzz_parity.py
+            llr[0] = 0.0
+            llr[1] = np.where(np.arange(N) % 2 == 0, 1e3, -1e3)
+            llr[2] *= 1e-3
+        want = o.decode_scl_llr(llr, L)
+        g.debug_set("lat_max_b", 1 << 40)
+        got = g.decode_scl_llr(llr, L)
+        g.debug_set("lat_max_b", -1)
+        ref = g.decode_scl_llr(llr, L)
+        rows = np.nonzero((want != got).any(axis=1))[0]
+        ordinary = [int(r) for r in rows if not (deg and r < 3)]
+        total += B; bad += len(ordinary)
+        if ordinary or (got != ref).any():
+            fails.append((it, cfg, B, ordinary[:6], int((got != ref).any(axis=1).sum())))
+        g.close()
+    print(f"latency-kernel fuzz slice: 80 configurations, {total} codewords, {bad} mismatching ordinary rows")
+    assert not fails, fails
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("L", [1, 2, 4, 8, 32])
+def test_nan_and_conflicting_infinities_terminate_and_stay_in_their_row(built_lib, oracle_built, L):
+    """Rows holding NaN, or infinities of conflicting sign (inf - inf = NaN in the reference's g-node, PolarCode.cpp:449-450), are
+    outside any meaningful domain: the reference's own std::sort over NaN metrics violates its ordering contract (the C
+    restatement does not even return on such a row), so there is nothing to compare with. What the kernels owe the caller is to
+    TERMINATE and to leave every other row of the batch exactly as it is without the bad rows — batch kernels and the
+    one-codeword-per-wave kernels alike."""
+    import ctypes as C
+    import polar_amd
+    from oracle_lib import Oracle
+    o = Oracle(9, 181, 0.32, 16, srand=1)
+    C.CDLL(None).srand(C.c_uint(1))
+    g = polar_amd.PolarCode(9, 181, 0.32, 16)
+    llr, _ = o.synth_llr(3052, 0, 40, o.snr_sqrt_linear(2.0))
+    want = o.decode_scl_llr(llr, L)
+    bad = llr.copy()
+    bad[2, ::5] = np.inf * np.sign(bad[2, ::5] + 1e-300)          # mostly the right signs, some wrong: NaN in g
+    bad[7, 3] = np.nan
+    bad[11, 0], bad[11, 1] = np.inf, -np.inf
+    bad[20] = np.nan
+    ok = np.ones(40, bool); ok[[2, 7, 11, 20]] = False
+    for lat in (-1, 1 << 40):
+        g.debug_set("lat_max_b", lat)
+        got = g.decode_scl_llr(bad, L)
+        assert (got[ok] == want[ok]).all(), lat
+    g.debug_set("lat_max_b", 0)

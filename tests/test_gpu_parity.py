@@ -3,7 +3,7 @@ Bit-exact bar: decoded info bits, encoder output and synthetic LLRs must be iden
 import numpy as np
 import pytest
 
-from golden_util import both_l1_kernels
+from golden_util import both_kernels, both_l1_kernels
 
 pytestmark = pytest.mark.gpu
 
@@ -48,7 +48,7 @@ def test_decode_scl_llr_matches_oracle(built_lib, oracle_built, n, K, crc, L):
     for ebno in (1.0, 2.0):
         llr, info = o.synth_llr(1234 + L, 0, B, o.snr_sqrt_linear(ebno))
         want = o.decode_scl_llr(llr, L)
-        got = both_l1_kernels(g, lambda: g.decode_scl_llr(llr, L)) if L == 1 else g.decode_scl_llr(llr, L)
+        got = both_kernels(g, lambda: g.decode_scl_llr(llr, L)) if L <= 8 else g.decode_scl_llr(llr, L)
         bad = np.nonzero((want != got).any(axis=1))[0]
         assert bad.size == 0, f"{bad.size}/{B} codewords differ (first {bad[:5]}) n={n} K={K} crc={crc} L={L} ebno={ebno}"
 
@@ -58,7 +58,8 @@ def test_odd_list_sizes_match_oracle(built_lib, oracle_built, L):
     """The reference accepts any list size (not only powers of two)."""
     o, g = _pair(9, 256, 8)
     llr, _ = o.synth_llr(4321, 50, 40, o.snr_sqrt_linear(1.0))
-    assert (o.decode_scl_llr(llr, L) == g.decode_scl_llr(llr, L)).all()
+    got = both_kernels(g, lambda: g.decode_scl_llr(llr, L)) if L <= 8 else g.decode_scl_llr(llr, L)
+    assert (o.decode_scl_llr(llr, L) == got).all()
 
 
 @pytest.mark.parametrize("L", [17, 24, 31])
@@ -80,7 +81,7 @@ def test_ragged_batches_and_empty(built_lib, oracle_built):
     llr, _ = o.synth_llr(9, 0, 131, o.snr_sqrt_linear(1.5))
     want = o.decode_scl_llr(llr, 8)
     for B in (1, 2, 3, 7, 9, 63, 65, 131):       # not multiples of the codewords-per-wave
-        assert (g.decode_scl_llr(llr[:B], 8) == want[:B]).all()
+        assert (both_kernels(g, lambda: g.decode_scl_llr(llr[:B], 8)) == want[:B]).all()
     assert g.decode_scl_llr(llr[:0], 8).shape == (0, 128)
     # single-vector form
     assert (g.decode_scl_llr(llr[5], 8) == want[5]).all()
@@ -220,13 +221,17 @@ def test_winning_path_metric_matches_oracle(built_lib, oracle_built, n, K, crc, 
     d = torch.tensor(llr, device="cuda")
     out = torch.empty((B, K), dtype=torch.uint8, device="cuda")
     pm = torch.zeros(B, dtype=torch.float64, device="cuda")
-    g.decode_scl_llr_dev(d.data_ptr(), B, L, out.data_ptr(), pm.data_ptr())
-    torch.cuda.synchronize()
-    got = pm.cpu().numpy()
-    for i in range(B):
-        bits, want = o.decode_scl_llr_pm(llr[i], L)
-        assert (out[i].cpu().numpy() == bits).all()
-        assert abs(got[i] - want) <= 1e-10 * max(1.0, abs(want)), (i, got[i], want)
+    for lat in ((-1, 1 << 40) if L <= 8 else (0,)):           # the batch kernel, the one-codeword-per-wave kernel (list sizes 2 .. 8)
+        g.debug_set("lat_max_b", lat)
+        out.zero_(); pm.zero_()
+        g.decode_scl_llr_dev(d.data_ptr(), B, L, out.data_ptr(), pm.data_ptr())
+        torch.cuda.synchronize()
+        got = pm.cpu().numpy()
+        for i in range(B):
+            bits, want = o.decode_scl_llr_pm(llr[i], L)
+            assert (out[i].cpu().numpy() == bits).all()
+            assert abs(got[i] - want) <= 1e-10 * max(1.0, abs(want)), (i, got[i], want)
+    g.debug_set("lat_max_b", 0)
 
 
 def test_no_finite_candidate_and_a_list_that_never_filled(built_lib, oracle_built):
@@ -281,7 +286,7 @@ def test_tiny_block_lengths(built_lib, oracle_built, n, K, crc):
     o, g = _pair(n, K, crc)
     llr, _ = o.synth_llr(5, 0, 300, o.snr_sqrt_linear(1.0))
     for L in (1, 2, 4, 8, 32):
-        got = both_l1_kernels(g, lambda: g.decode_scl_llr(llr, L)) if L == 1 else g.decode_scl_llr(llr, L)
+        got = both_kernels(g, lambda: g.decode_scl_llr(llr, L)) if L <= 8 else g.decode_scl_llr(llr, L)
         assert (o.decode_scl_llr(llr, L) == got).all(), L
 
 
@@ -342,7 +347,7 @@ def test_float32_llr_boundary(built_lib, oracle_built, n, K, crc, L):
     f = llr.astype(np.float32)
     f[0, :4] = [0.0, -0.0, np.float32(1e-30), np.float32(-3e38)]
     want = o.decode_scl_llr(f.astype(np.float64), L)
-    assert ((both_l1_kernels(g, lambda: g.decode_scl_llr(f, L)) if L == 1 else g.decode_scl_llr(f, L)) == want).all()
+    assert ((both_kernels(g, lambda: g.decode_scl_llr(f, L)) if L <= 8 else g.decode_scl_llr(f, L)) == want).all()
     d = torch.tensor(f, device="cuda")
     out = torch.empty((B, K), dtype=torch.uint8, device="cuda")
     g.decode_scl_llr_dev_f32(d.data_ptr(), B, L, out.data_ptr())
@@ -384,7 +389,7 @@ def test_degenerate_rows_mixed_with_normal_ones(built_lib, oracle_built, L):
     rows = rng.choice(384, len(special), replace=False)
     for r, s in zip(rows, special):
         llr[r] = s
-    got = both_l1_kernels(g, lambda: g.decode_scl_llr(llr, L)) if L == 1 else g.decode_scl_llr(llr, L)
+    got = both_kernels(g, lambda: g.decode_scl_llr(llr, L)) if L <= 8 else g.decode_scl_llr(llr, L)
     bad = [int(r) for r in range(384) if (got[r] != o.decode_scl_llr(llr[r], L)).any()]
     assert not bad, f"rows {bad} differ (special rows: {sorted(int(r) for r in rows)})"
 
@@ -400,8 +405,8 @@ def test_one_codeword_at_a_time_equals_the_batch(built_lib, oracle_built, L):
     assert (batch == o.decode_scl_llr(llr, L)).all()
     for i in range(24):
         assert (g.decode_scl_llr(llr[i], L) == batch[i]).all(), i          # (L = 1: the one-codeword-per-wave kernel, round 4)
-    if L == 1:
-        g.debug_set("lat_max_b", -1)                                       # ... and the eight-codewords-per-wave kernel with B = 1
+    if L <= 8:
+        g.debug_set("lat_max_b", -1)                                       # ... and the batch kernel with B = 1
         for i in range(24):
             assert (g.decode_scl_llr(llr[i], L) == batch[i]).all(), i
         g.debug_set("lat_max_b", 0)

@@ -31,11 +31,12 @@ for L in [int(x) for x in os.environ.get("LAT_LS", "1,4,32").split(",")]:
     want = cpu.decode_scl_llr(llr_all[:nc], L)
     cpu_per = (time.perf_counter() - t) / nc
     cross = None
-    for B in (1, 8, 64, 512, 1024, 2048, 4096):
+    for B in (1, 8, 64, 128, 256, 512, 1024, 2048, 4096):
         llr = np.ascontiguousarray(llr_all[:B])
-        # list size 1 has two kernels (round 4): one codeword per wave (small batches) and eight per wave; "auto" is what a
-        # caller gets, the other two rows force one of them (polar_debug_set "lat_max_b") to show the crossover
-        for variant, knob in ((("auto", 0), ("eight codewords per wave", -1), ("one codeword per wave", 1 << 40)) if L == 1 else (("auto", 0),)):
+        # list sizes 1 ... 8 have two kernels (round 4): one codeword per wave with the state in LDS (small batches) and the batch
+        # kernels; "auto" is what a caller gets, the other two rows force one of them (polar_debug_set "lat_max_b") to show the
+        # crossover (list sizes 2 ... 8: the forced latency kernel still needs its state to fit the LDS, else the batch kernel runs)
+        for variant, knob in ((("auto", 0), ("batch kernel", -1), ("one codeword per wave", 1 << 40)) if L <= 8 else (("auto", 0),)):
             g.debug_set("lat_max_b", knob)
             got = g.decode_scl_llr(llr, L)                       # warm-up (allocations) + check
             m = min(B, nc)
