@@ -85,7 +85,12 @@ int polar_encode_batch_dev(polar_code_t *h, const uint8_t *d_info, long B, uint8
  * 1 <= L <= POLAR_MAX_LIST.  out[K] = decoded information bits in the reference's order
  * (Info[_channel_order_descending[beta]], PolarCode.cpp:172-174). */
 int polar_decode_scl_llr(polar_code_t *h, const double *llr /*[N]*/, int L, uint8_t *out /*[K]*/);
-/* batched, row-major, codeword-contiguous: llr[B*N] -> out[B*K] */
+/* batched, row-major, codeword-contiguous: llr[B*N] -> out[B*K].
+ * Small batches — the reference's own loops decode one codeword per call (PolarCode.cpp:756,
+ * PolarM/main_MC_CC_Comparison.m:96) — take latency kernels with ONE codeword per wave and the decoder state in LDS: list size 1
+ * up to 2048 codewords (N <= 4096), list sizes 2 .. 8 up to one codeword per CU while the state fits 160 KiB of LDS (N = 2048: lists
+ * up to 4; N = 1024: up to 8). Same bits as the batch kernels (tests/: every such test runs both). Batches of at most 64
+ * codewords at list size 1 are staged in pinned, device-mapped host memory (no DMA copies). */
 int polar_decode_scl_llr_batch(polar_code_t *h, const double *llr, long B, int L, uint8_t *out);
 /* device-resident: d_llr/d_out live in HBM; asynchronous on `stream` (hipStream_t).
  * d_pm (optional, may be NULL) receives the winning path metric per codeword. */
@@ -246,7 +251,8 @@ int polar_set_mode(polar_code_t *h, int mode);
  * valid) and this function the count. */
 int polar_debug_weak_leaves(const polar_code_t *h);
 /* test / measurement hooks. polar_debug_set: the knobs above after creation ("mode_override" -1|0|1|2, "sc_no_fold",
- * "no_tables", "no_rccl", "force_rccl") and the ones that deliberately have NO environment form: "share_device" (one GPU
+ * "no_tables", "no_prefix", "no_rccl", "force_rccl"; "lat_max_b": largest batch that takes the one-codeword-per-wave kernels,
+ * 0 = default, -1 = never) and the ones that deliberately have NO environment form: "share_device" (one GPU
  * may be listed several times in a device list), "fail_device" = d / "fail_collective" = d (worker d reports a failure in
  * its second round before / after the barrier that precedes the counter reduction; -1 = off), "multi_timeout_s".
  * polar_debug_get: "allocs" (hipMalloc calls of all handles' scratch so far), "comm_inits", "weak_leaves",

@@ -744,7 +744,9 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
     // LDS (scl_decode_llr_kernel<.., LAT = 1>; exp-domain arithmetic for groups of 4 and 8 lanes, LLR-domain for groups of 2). The
     // kernel converts the channel itself (no conversion pass, no prefix kernel).
     const bool lat_list = (gs == 2 ? !ed : (ed && (gs == 4 || gs == 8))) && h->knobs.lat_max_b >= 0 &&
-                          B <= (h->knobs.lat_max_b ? h->knobs.lat_max_b : 96) && polar_decode_lat_lds_bytes(h->N, gs, h->W) <= (size_t)160 * 1024;
+                          B <= (h->knobs.lat_max_b ? h->knobs.lat_max_b : (long)h->num_cu) && polar_decode_lat_lds_bytes(h->N, gs, h->W) <= (size_t)160 * 1024;
+    // (measured, N = 2048: L = 4 B = 1 ... 256 2.45 ... 2.59 ms against 3.87 ... 4.36 ms for the batch kernel, L = 2 2.9 ... 3.0 against
+    // 5.9 ... 6.9 ms; from two waves per CU on — B = 512 — the batch kernel wins: the default is one wave per CU)
     if (lat_list) {
         PolarDecodeParams pl = p;
         pl.prefix_q = 0; pl.prefix_len = 0; pl.pre = nullptr;

@@ -79,7 +79,7 @@ def seed():
 def both_kernels(g, decode):
     """The list sizes 1 ... 8 have two kernels behind one entry point: the batch kernels (many codewords per wave, the big layers
     in an HBM scratch: throughput) and the latency kernels (ONE codeword per wave, its elements spread over the lanes, the state in
-    LDS: list size 1 up to 2048 codewords and N <= 4096, list sizes 2 ... 8 up to 96 codewords while the state fits the LDS).
+    LDS: list size 1 up to 2048 codewords and N <= 4096, list sizes 2 ... 8 up to one codeword per CU while the state fits the LDS).
     `decode()` is run with each of them forced ("lat_max_b" hook of polar_debug_set: -1 = never, a huge value = whenever the
     shape allows) and must return the same bits; returns them."""
     g.debug_set("lat_max_b", -1)
