@@ -504,11 +504,11 @@ OTHER_CONFIGS = {
     "config1": (9, 256, 0, 1, 262144, 2.0, "bpsk", "sc8_decode_kernel", 4096),
     "config2": (11, 1024, 0, 1, 65536, 2.0, "bpsk", "sc8_decode_kernel", 4096),        # 4 096-codeword CPU prefix
     "config2_b262144": (11, 1024, 0, 1, 262144, 2.0, "bpsk", "sc8_decode_kernel", 0),
-    "config3": (11, 1024, 16, 4, 65536, 2.0, "bpsk", "scl_decode_llr_kernel<4, 3, 0, true>", 2048),
-    "config5": (10, 512, 0, 8, 65536, 13.0, "ask16-gray", "scl_decode_llr_kernel<8, 3, 0, true>", 2048),
+    "config3": (11, 1024, 16, 4, 65536, 2.0, "bpsk", "scl_decode_llr_kernel<4, 3, 0, true, 0, 0>", 2048),
+    "config5": (10, 512, 0, 8, 65536, 13.0, "ask16-gray", "scl_decode_llr_kernel<8, 3, 0, true, 0, 0>", 2048),
     # the same at four times the batch (the tail of the persistent launch amortised; no CPU sample)
-    "config3_b262144": (11, 1024, 16, 4, 262144, 2.0, "bpsk", "scl_decode_llr_kernel<4, 3, 0, true>", 0),
-    "config5_b262144": (10, 512, 0, 8, 262144, 13.0, "ask16-gray", "scl_decode_llr_kernel<8, 3, 0, true>", 0),
+    "config3_b262144": (11, 1024, 16, 4, 262144, 2.0, "bpsk", "scl_decode_llr_kernel<4, 3, 0, true, 0, 0>", 0),
+    "config5_b262144": (10, 512, 0, 8, 262144, 13.0, "ask16-gray", "scl_decode_llr_kernel<8, 3, 0, true, 0, 0>", 0),
 }
 
 
