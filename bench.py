@@ -56,6 +56,10 @@ def main():
     ap.add_argument("--dry-run-gloo", action="store_true",
                     help="launcher / rendezvous / counter all-reduce only, on CPU over gloo: no kernel runs, the line carries "
                          "\"dry_run\": true and no throughput (tests/test_bench_launcher.py)")
+    ap.add_argument("--shared-gpu-gloo", action="store_true",
+                    help="TEST MODE for boxes with one GPU: the N ranks of the launch all use cuda:0 and reduce over gloo — the real "
+                         "kernels, the real strided shards, the same launcher, barriers and legs as an N-GPU run; the line carries "
+                         "\"shared_gpu_test\": true and its rates mean nothing (tests/test_gpu_bench_ranks.py)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
@@ -63,7 +67,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher (one rank per GPU, RCCL over xGMI). Checked BEFORE
         # spawning, so that a box with fewer GPUs fails here with one clear message instead of N tracebacks.
-        if not args.dry_run_gloo:
+        if not args.dry_run_gloo and not args.shared_gpu_gloo:
             have = torch.cuda.device_count() if torch.cuda.is_available() else 0
             if have < args.gpus:
                 raise SystemExit(f"bench.py: --gpus {args.gpus} requested but {have} GPU(s) visible; refusing to run "
@@ -87,6 +91,9 @@ def main():
         return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    shared = args.shared_gpu_gloo
+    if shared:
+        local_rank = 0                       # every rank on the one GPU of the box
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
@@ -104,7 +111,20 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if shared:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def allreduce(t, op=None):
+        """Sum / max over the ranks: RCCL on the device tensor; in the shared-GPU test mode through host memory over gloo."""
+        if not shared:
+            dist.all_reduce(t) if op is None else dist.all_reduce(t, op=op)
+            return t
+        c = t.cpu()
+        dist.all_reduce(c) if op is None else dist.all_reduce(c, op=op)
+        t.copy_(c)
+        return t
 
     from polar_amd import build
     if rank == 0 and not os.environ.get("POLAR_AMD_LIB"):
@@ -159,7 +179,7 @@ def main():
     for i in range(args.steps):
         step(i)
     if dist:
-        dist.all_reduce(counters)        # RCCL sum of the Monte-Carlo counters (xGMI)
+        allreduce(counters)              # RCCL sum of the Monte-Carlo counters (xGMI)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -167,7 +187,7 @@ def main():
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        allreduce(tmax, dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
     kern_ms = [a.elapsed_time(b) for a, b in ev]
@@ -238,10 +258,12 @@ def main():
 
     if args.mc_trials > 0:
         del llr, sent
-        res["monte_carlo"] = monte_carlo_leg(args, code, dist, dev, rank, world)
+        res["monte_carlo"] = monte_carlo_leg(args, code, dist, dev, rank, world, shared_gpu=shared)
         llr = torch.empty((B, N), dtype=torch.float64, device=dev)          # (the CPU baseline below re-checks the batch)
         code.synth_llr_dev(args.seed, trial0, B, s, llr.data_ptr(), 0)
         torch.cuda.synchronize()
+    if shared:
+        res["shared_gpu_test"] = True
     if rank == 0 and world == 1 and args.cpu_sample != 0:
         res["cpu_baseline"] = cpu_baseline(args, code, llr, out)
     if rank == 0 and world == 1 and not args.no_other_configs:
@@ -258,7 +280,7 @@ MC_GRID = [1.0, 1.25, 1.5, 1.75, 2.0]        # BASELINE configuration 4: Eb/N0 1
 MC_PREFIX = 65536
 
 
-def monte_carlo_leg(args, code, dist, dev, rank, world, engine=None, native=True):
+def monte_carlo_leg(args, code, dist, dev, rank, world, engine=None, native=True, shared_gpu=False):
     """End-to-end get_bler_quick, strong scaling: args.mc_trials trials in total whatever the world size, rounds of 262144
     trials per GPU, one all-reduce of the counters per round (PolarCode.cpp:696-775; the early stop of :725 is disabled by
     max_err so that every world size does the same work). Both drivers, and the sharded counters of a 65536-trial
@@ -274,6 +296,7 @@ def monte_carlo_leg(args, code, dist, dev, rank, world, engine=None, native=True
         if dev is not None:
             torch.cuda.synchronize()
 
+    red_dev = None if shared_gpu else dev       # (shared-GPU test mode: the process group is gloo, counters reduced on the host)
     host_group = None
     if dist is not None and world > 1:
         host_group = dist.new_group(backend="gloo")          # host-side barriers: no barrier kernel sits on the peers' GPUs
@@ -295,11 +318,11 @@ def monte_carlo_leg(args, code, dist, dev, rank, world, engine=None, native=True
                        f"generation + encoding + channel + decode + counting on the device",
            "total_trials": total, "n_gpus": world}
     # ---- multi-process driver (this launch: one rank per GPU)
-    get_bler_quick_sharded(engine, MC_GRID, Ls, max_runs=min(total, per_round), max_err=no_stop, seed=args.seed, global_batch=per_round, device=dev)   # warm-up (allocations)
+    get_bler_quick_sharded(engine, MC_GRID, Ls, max_runs=min(total, per_round), max_err=no_stop, seed=args.seed, global_batch=per_round, device=red_dev)   # warm-up (allocations)
     sync(); hbar()
     st = {}
     t0 = time.perf_counter()
-    bler, err, run = get_bler_quick_sharded(engine, MC_GRID, Ls, max_runs=total, max_err=no_stop, seed=args.seed, global_batch=per_round, device=dev, stats=st)
+    bler, err, run = get_bler_quick_sharded(engine, MC_GRID, Ls, max_runs=total, max_err=no_stop, seed=args.seed, global_batch=per_round, device=red_dev, stats=st)
     sync(); hbar()
     dt = tmax(time.perf_counter() - t0)
     out["multiprocess"] = {"driver": "polar_amd/montecarlo.py, one rank per GPU, torch.distributed all-reduce per round",
@@ -307,7 +330,7 @@ def monte_carlo_leg(args, code, dist, dev, rank, world, engine=None, native=True
                            "bler": [float(x) for x in bler[0]], "block_errors": [int(x) for x in err[0]], "runs": [int(x) for x in run[0]]}
     out["mc_trials_per_s"] = total / dt
     # ---- the same 65536-trial prefix: sharded over the ranks vs ONE GPU alone (rank 0)
-    _, e_sh, r_sh = get_bler_quick_sharded(engine, MC_GRID, Ls, max_runs=MC_PREFIX, max_err=no_stop, seed=args.seed, global_batch=MC_PREFIX, device=dev)
+    _, e_sh, r_sh = get_bler_quick_sharded(engine, MC_GRID, Ls, max_runs=MC_PREFIX, max_err=no_stop, seed=args.seed, global_batch=MC_PREFIX, device=red_dev)
     equal = {"multiprocess": None, "native_multi": None}
     e_one = r_one = None
     if rank == 0 and native:
@@ -319,6 +342,9 @@ def monte_carlo_leg(args, code, dist, dev, rank, world, engine=None, native=True
         try:
             code.debug_set("multi_timeout_s", 180)
             devs = list(range(world))
+            if shared_gpu:                                       # one GPU standing in for all of them (separate contexts, host-side sum)
+                code.debug_set("share_device", 1)
+                devs = [0] * world
             code.get_bler_quick(MC_GRID, Ls, max_runs=min(total, per_round), max_err=no_stop, seed=args.seed, batch=per_round, devices=devs)   # warm-up: contexts, communicators
             t0 = time.perf_counter()
             b2, c2 = code.get_bler_quick(MC_GRID, Ls, max_runs=total, max_err=no_stop, seed=args.seed, batch=per_round, devices=devs, return_counters=True)
