@@ -743,7 +743,10 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
     // Small batches of the small lists: ONE codeword per wave, its elements spread over the 64 / gs lanes of each path, the state in
     // LDS (scl_decode_llr_kernel<.., LAT = 1>; exp-domain arithmetic for groups of 4 and 8 lanes, LLR-domain for groups of 2). The
     // kernel converts the channel itself (no conversion pass, no prefix kernel).
-    const bool lat_list = (gs == 2 ? !ed : (ed && (gs == 4 || gs == 8))) && h->knobs.lat_max_b >= 0 &&
+    // (groups of 2 lanes: the batch path is the LLR-domain kernel, but ONE codeword per wave is faster with the exp-domain nodes — 2.2
+    // against 2.9 ms — so the latency form takes them unless mode 1 forces the LLR-domain arithmetic)
+    const bool lat_ed = (gs == 2) ? (mode != 1) : ed;
+    const bool lat_list = (gs == 2 || (ed && (gs == 4 || gs == 8))) && h->knobs.lat_max_b >= 0 &&
                           B <= (h->knobs.lat_max_b ? h->knobs.lat_max_b : (long)h->num_cu) && polar_decode_lat_lds_bytes(h->N, gs, h->W) <= (size_t)160 * 1024;
     // (measured, N = 2048: L = 4 B = 1 ... 256 2.45 ... 2.59 ms against 3.87 ... 4.36 ms for the batch kernel, L = 2 2.9 ... 3.0 against
     // 5.9 ... 6.9 ms; from two waves per CU on — B = 512 — the batch kernel wins: the default is one wave per CU)
@@ -751,7 +754,7 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
         PolarDecodeParams pl = p;
         pl.prefix_q = 0; pl.prefix_len = 0; pl.pre = nullptr;
         const int blocks = (int)std::min<long>(B, (long)h->num_cu);
-        if (ed) {
+        if (lat_ed) {
             if ((rc = h->d_flags.ensure((size_t)B))) return rc;
             if ((rc = h->d_list.ensure((size_t)B))) return rc;
             if ((rc = h->d_count.ensure(1))) return rc;
@@ -760,11 +763,11 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
         if (phase != 2) {
             HIP_TRY(hipMemsetAsync(p.work, 0, sizeof(unsigned int), st));
             if (ev_start) HIP_TRY(hipEventRecord((hipEvent_t)ev_start, st));
-            HIP_TRY(polar_launch_decode_lat(pl, gs, ed, blocks, st));
+            HIP_TRY(polar_launch_decode_lat(pl, gs, lat_ed, blocks, st));
             if (ev_stop) HIP_TRY(hipEventRecord((hipEvent_t)ev_stop, st));
-            if (!ed) return POLAR_OK;
+            if (!lat_ed) return POLAR_OK;
             if (phase == 1 && deferred) { *deferred = 2; return POLAR_OK; }        // (flag BYTES in d_flags: the caller looks)
-        } else if (!ed) return POLAR_OK;
+        } else if (!lat_ed) return POLAR_OK;
         HIP_TRY(hipMemsetAsync(h->d_count.p, 0, sizeof(unsigned int), st));
         HIP_TRY(polar_launch_ed_collect(h->d_flags.p, B, n_dev, h->d_list.p, h->d_count.p, st));
         HIP_TRY(hipMemsetAsync(p.work, 0, sizeof(unsigned int), st));

@@ -263,6 +263,11 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     constexpr int WPB = PIPE ? 1 : 4;
     constexpr int G = LAT ? 1 : 64 / GS;           // codewords per wave
     constexpr int EL = 64 / GS;                    // (LAT) lanes that share the elements of a path's layers
+    // partial-sum and history words: one column per LANE ([word][64]); LAT: per PATH ([word][GS] — the 64 / GS lanes of a path hold
+    // the same words and write the same values to the same place)
+    constexpr int CST = LAT ? GS : 64;
+#define POLAR_CL (LAT ? lig : lane)
+#define POLAR_CGB (LAT ? 0 : gbase)
     constexpr int SL = 1 << LDS_LOG;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave in block (uniform: keeps every per-wave base pointer in SGPRs)
@@ -278,8 +283,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     double *tabs = reinterpret_cast<double *>(smem);                           // T[64] RC[129] LC[129] (+2 pad), per block
     constexpr size_t WAVE_LDS = (size_t)(2 * SL - 1) * 64 * 8 + 128 * 8 + 128;  // bytes per wave
     unsigned char *wbase = smem + 324 * 8 + (size_t)wib * WAVE_LDS;
-    double *lds_llr = reinterpret_cast<double *>(wbase);                       // [(2*SL-1)][64]
-    double *sortbuf = lds_llr + (size_t)(2 * SL - 1) * 64;                     // [128]
+    double *lds_llr = reinterpret_cast<double *>(wbase);                       // [(2*SL-1)][64] (LAT: not there — its layers are lat_a)
+    double *sortbuf = lds_llr + (LAT ? 0 : (size_t)(2 * SL - 1) * 64);         // [128]
     // (plain pointers, ordered by wave_mem_fence(): a volatile-qualified pointer loses its LDS address
     // space and every access becomes a system-coherent FLAT operation that waits for all memory)
     unsigned char *stackv = reinterpret_cast<unsigned char *>(sortbuf + 128);   // [64]
@@ -313,10 +318,10 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     double *lat_a = lat_ch + N;                                                // (LAT) layers: size S at (S - 1) GS, element j of slot s at (j GS + s)
     uint32_t *lat_w = reinterpret_cast<uint32_t *>(lat_a + (size_t)N * GS);
     uint32_t *g_cl = LAT ? lat_w : p.c_scr + (size_t)wave_id * 2 * (size_t)cwords * 64;
-    uint32_t *g_cr = g_cl + (size_t)cwords * 64;
-    uint32_t *g_hist = LAT ? g_cr + (size_t)cwords * 64 : p.hist_scr + (size_t)wave_id * 3 * (size_t)p.W * 64;    // decision words [W][64]
-    uint32_t *g_horg = g_hist + (size_t)p.W * 64;                              // link to the previous word's slot
-    uint32_t *g_tb = g_horg + (size_t)p.W * 64;                                // winner's words, per-lane copy
+    uint32_t *g_cr = g_cl + (size_t)cwords * CST;
+    uint32_t *g_hist = LAT ? g_cr + (size_t)cwords * CST : p.hist_scr + (size_t)wave_id * 3 * (size_t)p.W * 64;    // decision words [W][64]
+    uint32_t *g_horg = g_hist + (size_t)p.W * CST;                             // link to the previous word's slot
+    uint32_t *g_tb = g_horg + (size_t)p.W * CST;                               // winner's words, per-lane copy
     // ---- table mode (list size 17..32, N >= 1024, exp-domain): layers 1 and 2 are never stored per path.
     // Every path's layer-1 value x1[e] = g(ch, ch', u1[e]) is one of TWO numbers, its layer-2 value one of 2 / 4 / 8
     // (phi = N/4: g of the shared first-half layer 1 with u2[j]; phi = N/2: f(x1[j], x1[j+N/4]) -> u1[j], u1[j+N/4];
@@ -450,14 +455,14 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                         X = nw;
                     } else if (S == 32) {
                         uint32_t cl = (uint32_t)(clsmall >> 32);
-                        uint32_t *dst = (to_right ? g_cr : g_cl) + (size_t)0 * 64 + lane;   // layer size 64 -> word offset 0
-                        if (active) { dst[0] = cl ^ X; dst[64] = X; }
+                        uint32_t *dst = (to_right ? g_cr : g_cl) + (size_t)0 * CST + POLAR_CL;   // layer size 64 -> word offset 0
+                        if (active) { dst[0] = cl ^ X; dst[CST] = X; }
                         if (!to_right && active) pC.set(sh + 1, lig);
                     } else {
                         const int nwd = S / 32;
-                        const uint32_t *cl = g_cl + (size_t)(nwd - 2) * 64 + gbase + pC.get(sh);
-                        const uint32_t *cr = g_cr + (size_t)(nwd - 2) * 64 + lane;
-                        uint32_t *dst = (to_right ? g_cr : g_cl) + (size_t)(2 * nwd - 2) * 64 + lane;
+                        const uint32_t *cl = g_cl + (size_t)(nwd - 2) * CST + POLAR_CGB + pC.get(sh);
+                        const uint32_t *cr = g_cr + (size_t)(nwd - 2) * CST + POLAR_CL;
+                        uint32_t *dst = (to_right ? g_cr : g_cl) + (size_t)(2 * nwd - 2) * CST + POLAR_CL;
                         if (active) {
                             // all loads of a chunk first, then the stores: one memory round trip per chunk instead of
                             // one per word (a load behind a store waits for the store's acknowledgement as well)
@@ -466,9 +471,9 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                                 for (int w = 0; w < nwd; w += CH) {
                                     uint32_t r[CH], l[CH];
 #pragma unroll
-                                    for (int i = 0; i < CH; ++i) { r[i] = cr[(size_t)(w + i) * 64]; l[i] = cl[(size_t)(w + i) * 64]; }
+                                    for (int i = 0; i < CH; ++i) { r[i] = cr[(size_t)(w + i) * CST]; l[i] = cl[(size_t)(w + i) * CST]; }
 #pragma unroll
-                                    for (int i = 0; i < CH; ++i) { dst[(size_t)(w + i) * 64] = l[i] ^ r[i]; dst[(size_t)(w + i + nwd) * 64] = r[i]; }
+                                    for (int i = 0; i < CH; ++i) { dst[(size_t)(w + i) * CST] = l[i] ^ r[i]; dst[(size_t)(w + i + nwd) * CST] = r[i]; }
                                 }
                             };
                             if (nwd >= 8) chunk(std::integral_constant<int, 8>{});
@@ -503,11 +508,11 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     const double *srcp = (lam > 1) ? lat_a + (size_t)(2 * S_ - 1) * GS + pin_ : lat_ch;
                     const int sstr = (lam > 1) ? GS : 1;
                     double *dstp = lat_a + (size_t)(S_ - 1) * GS + lig;
-                    const uint32_t *cwp_ = (odd_ && S_ > 32) ? g_cl + (size_t)(S_ / 32 - 2) * 64 + gbase + pC.get(sh_) : nullptr;
+                    const uint32_t *cwp_ = (odd_ && S_ > 32) ? g_cl + (size_t)(S_ / 32 - 2) * CST + pC.get(sh_) : nullptr;
                     auto one = [&](int j, double a_, double b_) -> double {
                         if (!odd_) return FN(a_, b_);
                         if (S_ <= 32) return GN(a_, b_, (uint32_t)(clsmall >> S_), j);
-                        return GN(a_, b_, cwp_[(size_t)(j >> 5) * 64], j & 31);
+                        return GN(a_, b_, cwp_[(size_t)(j >> 5) * CST], j & 31);
                     };
                     if (S_ >= 4 * EL) {
                         for (int j0 = e_; j0 < S_; j0 += 4 * EL) {
@@ -532,6 +537,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     if (active) pL.set(sh_, lig);
                     wave_mem_fence();
                     if (S_ == 1) leaf = lat_a[lig];            // (every lane of the path: the element-0 lane wrote it)
+                    PROF(S_ >= EL ? (odd_ ? 1 : 2) : (S_ >= 4 ? 3 : 4))
                     continue;
                 }
                 if (POLAR_UNLIKELY2(tbl && lam <= 2 && phi >= S2)) {
@@ -1406,8 +1412,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 if (POLAR_UNLIKELY2((t & 31) == 31)) {
                     const int w = (int)(t >> 5);
                     if (active) {
-                        g_hist[(size_t)w * 64 + lane] = hword;
-                        g_horg[(size_t)w * 64 + lane] = (uint32_t)origin;
+                        g_hist[(size_t)w * CST + POLAR_CL] = hword;
+                        g_horg[(size_t)w * CST + POLAR_CL] = (uint32_t)origin;
                         origin = lig;
                         hword = 0;
                     }
@@ -1431,8 +1437,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         // ---------------- last (partial) history word ----------------
         const int Wused = (int)((t + 31) >> 5);
         if ((t & 31) != 0 && active) {
-            g_hist[(size_t)(Wused - 1) * 64 + lane] = hword;
-            g_horg[(size_t)(Wused - 1) * 64 + lane] = (uint32_t)origin;
+            g_hist[(size_t)(Wused - 1) * CST + POLAR_CL] = hword;
+            g_horg[(size_t)(Wused - 1) * CST + POLAR_CL] = (uint32_t)origin;
         }
         wave_mem_fence();
 
@@ -1444,8 +1450,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
             if (active) {
                 int cur = lig;
                 for (int w = Wused - 1; w >= 0; --w) {
-                    const uint32_t hw = g_hist[(size_t)w * 64 + gbase + cur];
-                    cur = (int)(g_horg[(size_t)w * 64 + gbase + cur] & (GS - 1));
+                    const uint32_t hw = g_hist[(size_t)w * CST + POLAR_CGB + cur];
+                    cur = (int)(g_horg[(size_t)w * CST + POLAR_CGB + cur] & (GS - 1));
                     for (int i = 0; i < p.crc; ++i)
                         acc ^= (uint32_t)(__popc(hw & p.crc_mask[(size_t)i * p.W + w]) & 1) << i;
                 }
@@ -1486,15 +1492,15 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
             // the same list, so the loads are broadcasts), then the K info bits by unfrozen rank
             int cur = win;
             for (int w = Wused - 1; w >= 0; --w) {
-                g_tb[(size_t)w * 64 + lane] = g_hist[(size_t)w * 64 + gbase + cur];
-                cur = (int)(g_horg[(size_t)w * 64 + gbase + cur] & (GS - 1));   // (stale slots of idle groups stay in range)
+                g_tb[(size_t)w * CST + POLAR_CL] = g_hist[(size_t)w * CST + POLAR_CGB + cur];
+                cur = (int)(g_horg[(size_t)w * CST + POLAR_CGB + cur] & (GS - 1));   // (stale slots of idle groups stay in range)
             }
             wave_mem_fence();
         }
         if (valid) {
             for (int b = LAT ? lane : lig; b < K; b += LAT ? 64 : GS) {
                 unsigned r = p.info_rank[b];
-                uint32_t wd = g_tb[(size_t)(r >> 5) * 64 + lane];
+                uint32_t wd = g_tb[(size_t)(r >> 5) * CST + POLAR_CL];
                 p.out[(size_t)cw * K + b] = win_active ? (uint8_t)((wd >> (r & 31)) & 1u) : (uint8_t)0;
             }
         }
@@ -1805,19 +1811,17 @@ static hipError_t launch_gs(const PolarDecodeParams &p, int lds_log, int pipe, i
 // file compiled with POLAR_ED_TU = 1), LLR-domain for the groups of 2 (POLAR_ED_TU = 0)
 template <int GS, bool ED>
 static hipError_t launch_lat(const PolarDecodeParams &p, int blocks, hipStream_t st) {
-    const int cwords = (p.N >= 128) ? (p.N / 32 - 2) : 0;
-    const size_t lds = polar_decode_lds_bytes(3, 1) + (size_t)p.N * 8 + (size_t)p.N * GS * 8 + ((size_t)2 * cwords + (size_t)3 * p.W) * 64 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&scl_decode_llr_kernel<GS, 3, 1, ED, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    const size_t lds = polar_decode_lat_lds_bytes(p.N, GS, p.W);
+    // (per launch, not once per process: the attribute belongs to the function ON THE CURRENT DEVICE, and the multi-device Monte-Carlo
+    // driver launches from one thread per device)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&scl_decode_llr_kernel<GS, 3, 1, ED, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((scl_decode_llr_kernel<GS, 3, 1, ED, 0, 1>), dim3(blocks), dim3(64), lds, st, p);
     return hipGetLastError();
 }
 #if POLAR_ED_TU == 1
 hipError_t polar_launch_decode_lat_ed1(const PolarDecodeParams &p, int gs, int blocks, hipStream_t st) {
     switch (gs) {
+        case 2: return launch_lat<2, true>(p, blocks, st);
         case 4: return launch_lat<4, true>(p, blocks, st);
         case 8: return launch_lat<8, true>(p, blocks, st);
         default: return hipErrorInvalidValue;
@@ -1832,7 +1836,8 @@ hipError_t polar_launch_decode_lat(const PolarDecodeParams &p, int gs, bool ed, 
 }
 size_t polar_decode_lat_lds_bytes(int N, int gs, int W) {
     const int cwords = (N >= 128) ? (N / 32 - 2) : 0;
-    return polar_decode_lds_bytes(3, 1) + (size_t)N * 8 + (size_t)N * gs * 8 + ((size_t)2 * cwords + (size_t)3 * W) * 64 * 4;
+    // tables + exchange buffers + converted channel + layers + partial-sum and history words (one column per path)
+    return 324 * 8 + (128 * 8 + 128) + (size_t)N * 8 + (size_t)N * gs * 8 + ((size_t)2 * cwords + (size_t)3 * W) * gs * 4 + 64;
 }
 #endif
 

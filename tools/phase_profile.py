@@ -37,6 +37,8 @@ names = ["loop ovh", "layer S>SL g (HBM)", "layer S>SL f (HBM)", "layer 4<=S<=SL
 print(f"L={L} B={B} time {dt*1e3:.2f} ms -> {B/dt:.0f} cw/s")
 cyc = a[:8].sum() + a[16:24].sum()
 nwd = B / (64 // max(1, 1 << (L - 1).bit_length()))      # wave-decodes
+if os.environ.get("LATPROF"):                             # the one-codeword-per-wave kernels: a wave-decode is a codeword
+    nwd = B
 print(f"  cycles per wave-decode: {cyc/nwd:.0f}")
 for nm, v in zip(names[:8], a[:8]):
     print(f"  {nm:34s} {100*v/cyc:5.1f}%  {v/nwd:10.0f} cycles/wave-decode")
