@@ -118,6 +118,7 @@ struct polar_code {
         int mode_override = -1;      // POLAR_MODE=<0|1|2>: replaces `mode`
         bool sc_no_fold = false;     // POLAR_SC_NO_FOLD: list size 1 decodes a permuted, converted copy (front pass)
         bool no_tables = false;      // POLAR_NO_TABLES: list of 17..32 without the layer-1/2 value tables
+        bool no_fuse_front = false;  // (hook) exp-domain lists: separate conversion pass in front of the prefix kernel (the round-3 path)
         bool no_rccl = false;        // POLAR_NO_RCCL: multi-device counters summed on the host
         bool force_rccl = false;     // POLAR_FORCE_RCCL: RCCL even with one device
         bool share_device = false;   // (test hook) one GPU may be listed several times: separate contexts, host-side sum
@@ -528,6 +529,7 @@ int polar_debug_set(polar_code_t *h, const char *key, long value) {
     if (s == "mode_override") { if (value < -1 || value > 2) return fail(POLAR_E_ARG, "mode_override must be -1 (none), 0, 1 or 2"); k.mode_override = (int)value; }
     else if (s == "sc_no_fold") k.sc_no_fold = value != 0;
     else if (s == "no_tables") k.no_tables = value != 0;
+    else if (s == "no_fuse_front") k.no_fuse_front = value != 0;
     else if (s == "no_prefix") h->prefix_on = (value == 0);          // (the all-frozen prefix decoded leaf by leaf by the list kernel itself)
     else if (s == "no_rccl") k.no_rccl = value != 0;
     else if (s == "force_rccl") k.force_rccl = value != 0;
@@ -746,14 +748,17 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
     // (groups of 2 lanes: the batch path is the LLR-domain kernel, but ONE codeword per wave is faster with the exp-domain nodes — 2.2
     // against 2.9 ms — so the latency form takes them unless mode 1 forces the LLR-domain arithmetic)
     const bool lat_ed = (gs == 2) ? (mode != 1) : ed;
-    const bool lat_list = (gs == 2 || (ed && (gs == 4 || gs == 8))) && h->knobs.lat_max_b >= 0 &&
-                          B <= (h->knobs.lat_max_b ? h->knobs.lat_max_b : (long)h->num_cu) && polar_decode_lat_lds_bytes(h->N, gs, h->W) <= (size_t)160 * 1024;
+    const size_t lat_lds = polar_decode_lat_lds_bytes(h->N, gs, h->W);
+    const long lat_resident = lat_lds <= (size_t)160 * 1024 ? (long)h->num_cu * std::min<long>(4, (long)(((size_t)160 * 1024) / lat_lds)) : 0;   // waves the LDS lets a device hold
+    const bool lat_list = (gs == 2 || (ed && (gs == 4 || gs == 8))) && h->knobs.lat_max_b >= 0 && lat_resident > 0 &&
+                          B <= (h->knobs.lat_max_b ? h->knobs.lat_max_b : lat_resident);
     // (measured, N = 2048: L = 4 B = 1 ... 256 2.45 ... 2.59 ms against 3.87 ... 4.36 ms for the batch kernel, L = 2 2.9 ... 3.0 against
-    // 5.9 ... 6.9 ms; from two waves per CU on — B = 512 — the batch kernel wins: the default is one wave per CU)
+    // 5.9 ... 6.9 ms; beyond the waves the LDS lets the device hold at once — one per CU for lists of 4 and 8 at N = 2048, three for
+    // lists of 2 — the batch kernel wins: that is the default threshold)
     if (lat_list) {
         PolarDecodeParams pl = p;
         pl.prefix_q = 0; pl.prefix_len = 0; pl.pre = nullptr;
-        const int blocks = (int)std::min<long>(B, (long)h->num_cu);
+        const int blocks = (int)std::min<long>(B, lat_resident);
         if (lat_ed) {
             if ((rc = h->d_flags.ensure((size_t)B))) return rc;
             if ((rc = h->d_list.ensure((size_t)B))) return rc;
@@ -779,7 +784,7 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
     }
     HIP_TRY(hipMemsetAsync(p.work, 0, sizeof(unsigned int), st));
     if (!ed) {
-        if (p.prefix_q) HIP_TRY(polar_launch_prefix(p, false, st));
+        if (p.prefix_q) HIP_TRY(polar_launch_prefix(p, false, nullptr, st));
         if (ev_start) HIP_TRY(hipEventRecord((hipEvent_t)ev_start, st));
         HIP_TRY(polar_launch_decode_llr(p, gs, lds_log, pipe, grid, false, st));
         if (ev_stop) HIP_TRY(hipEventRecord((hipEvent_t)ev_stop, st));
@@ -790,7 +795,9 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
     if ((rc = h->d_list.ensure((size_t)B))) return rc;
     if ((rc = h->d_count.ensure(1))) return rc;
     HIP_TRY(hipMemsetAsync(h->d_count.p, 0, sizeof(unsigned int), st));
-    HIP_TRY(polar_launch_ed_front(d_llr, llr_f32, h->d_ech.p, h->d_flags.p, h->d_tabs.p, h->N, B, n_dev, st));
+    // (round 4: where the prefix kernel's first pass is staged through LDS it converts the raw rows itself — no conversion pass)
+    const bool fuse_front = p.prefix_q > 0 && polar_prefix_is_staged(h->N) && !h->knobs.no_fuse_front;
+    if (!fuse_front) HIP_TRY(polar_launch_ed_front(d_llr, llr_f32, h->d_ech.p, h->d_flags.p, h->d_tabs.p, h->N, B, n_dev, st));
     PolarDecodeParams pe = p;
     pe.llr = h->d_ech.p; pe.llr_f32 = 0; pe.flags = h->d_flags.p;
     if (gs == 32 && !pipe && h->N >= 1024 && p.prefix_q > 0 && !h->knobs.no_tables) {
@@ -799,7 +806,11 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
         if ((rc = h->d_var_scr.ensure((size_t)grid * (h->N / 32) * 64 + 64))) return rc;
         pe.tab_scr = h->d_tab_scr.p; pe.var_scr = h->d_var_scr.p;
     }
-    if (pe.prefix_q) HIP_TRY(polar_launch_prefix(pe, true, st));
+    if (pe.prefix_q && fuse_front) {
+        PolarDecodeParams pp = pe;
+        pp.llr = (const double *)d_llr; pp.llr_f32 = llr_f32;
+        HIP_TRY(polar_launch_prefix(pp, true, h->d_ech.p, st));
+    } else if (pe.prefix_q) HIP_TRY(polar_launch_prefix(pe, true, nullptr, st));
     if (ev_start) HIP_TRY(hipEventRecord((hipEvent_t)ev_start, st));
     HIP_TRY(polar_launch_decode_llr(pe, gs, lds_log, pipe, grid, true, st));
     if (ev_stop) HIP_TRY(hipEventRecord((hipEvent_t)ev_stop, st));

@@ -35,9 +35,10 @@ struct PolarDecodeParams {
 
 size_t polar_decode_lds_bytes(int lds_log, int pipe);
 int polar_decode_waves_per_block(int pipe);
-hipError_t polar_launch_prefix(const PolarDecodeParams &p, bool ed, hipStream_t st);
-hipError_t polar_launch_prefix_ed0(const PolarDecodeParams &p, hipStream_t st);
-hipError_t polar_launch_prefix_ed1(const PolarDecodeParams &p, hipStream_t st);
+hipError_t polar_launch_prefix(const PolarDecodeParams &p, bool ed, double *ech_out, hipStream_t st);
+hipError_t polar_launch_prefix_ed0(const PolarDecodeParams &p, double *ech_out, hipStream_t st);
+hipError_t polar_launch_prefix_ed1(const PolarDecodeParams &p, double *ech_out, hipStream_t st);
+int polar_prefix_is_staged(int N);
 hipError_t polar_launch_decode_llr_ed0(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, hipStream_t st);
 hipError_t polar_launch_decode_llr_ed1(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, hipStream_t st);
 // one codeword per wave, state in LDS (the latency form; list sizes 2 .. 8 while polar_decode_lat_lds_bytes() fits 160 KiB)

@@ -1541,7 +1541,12 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
 // LLRs; (3) the path metric accumulated over the first Pe leaves in order, same operations and order
 // as continuePaths_FrozenBit (PolarCode.cpp:475-487) -> pre[cw][0].
 template <bool ED>
-__global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p, int staged) {
+// Round 4: (a) with ech_out (exp-domain, staged) the first pass reads the caller's RAW channel pairs, converts them (the input
+// guard of ed_front_kernel included), writes the stored form for the decode kernel and feeds the f-node from registers: the separate
+// conversion pass (a read and a write of the whole batch) is gone; (b) the layers below the first are computed from the staged copy
+// in LDS, in place (element j and j + S belong to the same lane), instead of from what was just written to global memory: the
+// write -> read round trip through the L2 between the layers of a codeword was the kernel's time.
+__global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p, int staged, double *ech_out) {
     __shared__ double tabs[324];
     // staged: the first pass (channel -> layer N/2) reads the channel pairs in their own order — element j of the layer comes
     // from the pair at bitrev(j), a 16-B read from a different line for every lane when read in element order — and
@@ -1569,17 +1574,50 @@ __global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p, int st
         const double *in0 = ch_row<ED>(p, (size_t)(valid ? cw : 0), N);
         double *pre = const_cast<double *>(p.pre) + (size_t)(valid ? cw : 0) * (size_t)(N - Q + 1);
         double x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        bool bad_in = false;                 // (fused conversion: this codeword's input guard)
         for (int S = N / 2; S >= Q; S >>= 1) {
             if (valid && staged && 2 * S == N) {
                 double *stg = pstage + (size_t)(threadIdx.x >> 5) * (size_t)S;
                 double *outp = pre + 1;
-                for (int m = lig; m < S; m += 32) {
-                    const double r = FN(CH(in0, 2 * m), CH(in0, 2 * m + 1));
-                    stg[__brev((unsigned)m) >> (33 - n)] = r;                  // element j = bitrev_{n-1}(m)
+                if (ED && ech_out) {
+                    double *erow = ech_out + (size_t)cw * (size_t)N;
+                    bool any = false, sized = false;
+                    for (int m = lig; m < S; m += 32) {
+                        const double x0 = CH(in0, 2 * m), x1 = CH(in0, 2 * m + 1);
+                        bool f0, f1;
+                        const double a = ed_from_channel(x0, tb, f0), b = ed_from_channel(x1, tb, f1);
+                        any |= f0 | f1;
+                        sized |= (fabs(x0) >= 0.1) | (fabs(x1) >= 0.1);
+                        erow[2 * m] = a; erow[2 * m + 1] = b;
+                        stg[__brev((unsigned)m) >> (33 - n)] = FN(a, b);       // element j = bitrev_{n-1}(m)
+                    }
+                    // input guard per codeword (ed_front_kernel): a non-finite or < 1e-9 value, or no value >= 0.1 at all
+                    const u64 m_any = __builtin_amdgcn_ballot_w64(any), m_sz = __builtin_amdgcn_ballot_w64(sized);
+                    const u64 half = gbase ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
+                    bad_in = ((m_any & half) != 0) || ((m_sz & half) == 0);
+                } else {
+                    for (int m = lig; m < S; m += 32) {
+                        const double r = FN(CH(in0, 2 * m), CH(in0, 2 * m + 1));
+                        stg[__brev((unsigned)m) >> (33 - n)] = r;              // element j = bitrev_{n-1}(m)
+                    }
                 }
                 wave_mem_fence();                                            // (the 32 lanes of a codeword are in one wave)
                 for (int j = lig; j < S; j += 32) {
                     const double r = stg[j];
+                    outp[j] = r;
+                    if (S == Q) {
+#pragma unroll
+                        for (int rr = 0; rr < 8; ++rr) if (rr == (j >> 5)) x[rr] = r;
+                    }
+                }
+                wave_mem_fence();
+            } else if (valid && staged) {
+                // the layer above is still in the staging row (elements [0, 2S)): in place, lane-local
+                double *stg = pstage + (size_t)(threadIdx.x >> 5) * (size_t)(N / 2);
+                double *outp = pre + 1 + (size_t)(N - 2 * S);
+                for (int j = lig; j < S; j += 32) {
+                    const double r = FN(stg[j], stg[j + S]);
+                    stg[j] = r;
                     outp[j] = r;
                     if (S == Q) {
 #pragma unroll
@@ -1682,7 +1720,9 @@ __global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p, int st
         }
         if (valid && lig == 0) pre[0] = acc;
         if constexpr (ED) {
-            if (valid && lig == 0 && ((guard >> gbase) & 0xFFFFFFFFull) != 0) p.flags[cw] = 1;
+            const bool fl = ((guard >> gbase) & 0xFFFFFFFFull) != 0;
+            if (ech_out) { if (valid && lig == 0) p.flags[cw] = (fl || bad_in) ? 1 : 0; }       // (no conversion pass has set it)
+            else if (valid && lig == 0 && fl) p.flags[cw] = 1;
             guard = 0;
         }
         wave_mem_fence();
@@ -1699,22 +1739,26 @@ __global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p, int st
 #endif
 #if POLAR_ED_TU != 2
 #if POLAR_ED_TU
-hipError_t polar_launch_prefix_ed1(const PolarDecodeParams &p, hipStream_t st) {
+hipError_t polar_launch_prefix_ed1(const PolarDecodeParams &p, double *ech_out, hipStream_t st) {
 #else
-hipError_t polar_launch_prefix_ed0(const PolarDecodeParams &p, hipStream_t st) {
+hipError_t polar_launch_prefix_ed0(const PolarDecodeParams &p, double *ech_out, hipStream_t st) {
 #endif
     long blocks = (p.B + 7) / 8;
     if (blocks > 8192) blocks = 8192;
     const size_t stage = (size_t)8 * (size_t)(p.N / 2) * sizeof(double);        // 64 KiB at N = 2048: two blocks per CU
-    const int staged = (p.N >= 64 && stage <= 64 * 1024) ? 1 : 0;
-    hipLaunchKernelGGL(prefix_kernel<POLAR_ED_TU != 0>, dim3((unsigned)blocks), dim3(256), staged ? stage : 0, st, p, staged);
+    const int staged = polar_prefix_is_staged(p.N);
+    if (ech_out && !staged) return hipErrorInvalidValue;                        // (the fused conversion exists for the staged first pass)
+    hipLaunchKernelGGL(prefix_kernel<POLAR_ED_TU != 0>, dim3((unsigned)blocks), dim3(256), staged ? stage : 0, st, p, staged, ech_out);
     return hipGetLastError();
 }
 #endif  // POLAR_ED_TU != 2
 
 #if !POLAR_ED_TU
-hipError_t polar_launch_prefix(const PolarDecodeParams &p, bool ed, hipStream_t st) {
-    return ed ? polar_launch_prefix_ed1(p, st) : polar_launch_prefix_ed0(p, st);
+int polar_prefix_is_staged(int N) { return (N >= 64 && (size_t)8 * (size_t)(N / 2) * sizeof(double) <= 64 * 1024) ? 1 : 0; }
+// ech_out (exp-domain only, staged block lengths only): p.llr are the caller's RAW rows; the kernel converts them, writes the stored
+// form there and sets p.flags (0 / 1) for every codeword — no ed_front_kernel before it
+hipError_t polar_launch_prefix(const PolarDecodeParams &p, bool ed, double *ech_out, hipStream_t st) {
+    return ed ? polar_launch_prefix_ed1(p, ech_out, st) : polar_launch_prefix_ed0(p, nullptr, st);
 }
 // ------------------------------------------------------------------------------------------
 // ed_front_kernel — channel LLRs -> stored form of the exp-domain kernel (p.llr -> p.ech), plus the

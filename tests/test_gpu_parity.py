@@ -485,3 +485,38 @@ def test_list_size_one_accepts_rows_that_are_not_16_byte_aligned(built_lib, orac
             g.decode_scl_llr_dev_f32(v.data_ptr(), B, 1, out.data_ptr())
             torch.cuda.synchronize()
             assert (out.cpu().numpy() == want32).all(), (off, lat)
+
+
+@pytest.mark.parametrize("n,K,crc", [(11, 1024, 16), (9, 256, 8), (10, 512, 0), (7, 40, 4)])
+@pytest.mark.parametrize("L", [4, 8, 32])
+def test_conversion_fused_into_the_prefix_pass(built_lib, oracle_built, n, K, crc, L):
+    """Round 4: for the exp-domain list kernels the all-frozen-prefix kernel converts the caller's raw channel rows itself (first
+    pass staged through LDS, N <= 2048) instead of reading what a separate conversion pass wrote, and computes the layers below
+    from the staged copy. Same bits as the round-3 sequence ("no_fuse_front" hook) and as the oracle, including the rows the input
+    guard hands to the LLR-domain kernel (zeros, a sub-1e-9 value, an infinity of the right sign, a row scaled by 1e-3), for
+    doubles and floats, and for a batch that is not a multiple of the eight codewords per block."""
+    o, g = _pair(n, K, crc)
+    N = 1 << n
+    B = 203
+    llr, _ = o.synth_llr(515 + L, 0, B, o.snr_sqrt_linear(1.5))
+    llr[3] = 0.0
+    llr[4, 5] = 1e-12
+    llr[5, 7] = np.inf * np.sign(llr[5, 7] + 1e-300)
+    llr[6] *= 1e-3
+    llr[200, 1] = 0.0
+    want = o.decode_scl_llr(llr, L)
+    g.debug_set("lat_max_b", -1)
+    got = g.decode_scl_llr(llr, L)
+    g.debug_set("no_fuse_front", 1)
+    old = g.decode_scl_llr(llr, L)
+    g.debug_set("no_fuse_front", 0)
+    ok = np.ones(B, bool); ok[6] = False        # (the "x 1e-3" row is decided at the reference's rounding noise: kernel vs kernel only)
+    assert (got == old).all() and (got[ok] == want[ok]).all()
+    f = llr.astype(np.float32)
+    want32 = o.decode_scl_llr(f.astype(np.float64), L)
+    got32 = g.decode_scl_llr(f, L)
+    g.debug_set("no_fuse_front", 1)
+    old32 = g.decode_scl_llr(f, L)
+    g.debug_set("no_fuse_front", 0)
+    assert (got32 == old32).all() and (got32[ok] == want32[ok]).all()
+    g.debug_set("lat_max_b", 0)
