@@ -268,6 +268,7 @@ def main():
         res["cpu_baseline"] = cpu_baseline(args, code, llr, out)
     if rank == 0 and world == 1 and not args.no_other_configs:
         res["other_configs"] = other_configs(args, dev)
+        res["one_codeword_per_call"] = latency_record(args, code)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -612,6 +613,35 @@ def run_config(name, args, dev, steps=3, with_cpu=True):
                                "gpu_vs_cpu_mismatching_codewords": int((ref_out != out[:cpu_n].cpu().numpy()).any(axis=1).sum())}
     del llr, sent, out
     return res
+
+
+def latency_record(args, code):
+    """The reference's own call pattern — ONE codeword per call (PolarCode.cpp:756, PolarM/main_MC_CC_Comparison.m:96) — through the
+    host-pointer ABI (staging + kernel + synchronisation + result copy), next to the CPU side on one core: median of 30 calls per
+    list size on codewords of the benchmark workload, bits checked against the CPU's."""
+    import ctypes as C
+    import oracle_lib
+    kind = "reference" if oracle_lib.have_reference() else "port"
+    C.CDLL(None).srand(C.c_uint(1))
+    cpu = (oracle_lib.Reference if kind == "reference" else oracle_lib.Oracle)(args.n, args.K, 0.32, args.crc, srand=1)
+    o = oracle_lib.Oracle(args.n, args.K, 0.32, args.crc, srand=1)
+    llr, _ = o.synth_llr(args.seed, 0, 8, o.snr_sqrt_linear(args.ebno))
+    rows = []
+    for L in (1, 2, 4, 8, 32):
+        t = time.perf_counter()
+        want = cpu.decode_scl_llr(llr, L)
+        cpu_ms = (time.perf_counter() - t) / len(llr) * 1e3
+        ok = True
+        ts = []
+        for i in range(30):
+            x = llr[i % 8]
+            t = time.perf_counter()
+            got = code.decode_scl_llr(x, L)
+            ts.append(time.perf_counter() - t)
+            ok = ok and bool((got == want[i % 8]).all())
+        rows.append({"L": L, "gpu_call_ms": float(np.median(ts)) * 1e3, "cpu_ms_per_codeword_one_core": cpu_ms, "cpu_kind": kind,
+                     "bits_equal": ok})
+    return {"abi": "polar_decode_scl_llr (host pointers, one codeword per call)", "rows": rows}
 
 
 def other_configs(args, dev):

@@ -64,3 +64,25 @@ def test_sharded_counters_equal_unsharded(oracle_built, tmp_path):
     # Monte-Carlo construction table: identical for 1 and 2 ranks (checked by a == b), and non-trivial
     cnt = np.array(a["cnt"])
     assert cnt.shape == (64,) and cnt[0] > 20 and cnt[-1] == 0
+
+
+def test_automatic_rounds_follow_the_native_driver():
+    """polar_amd/montecarlo.py takes the rounds of polar_host.cpp next_round(): `batch` trials over all ranks, or geometric —
+    max(256, 2 max_err) first (rounded up to a multiple of the world size), then as many as all rounds before, at most 262144 PER
+    RANK (round 3 capped the round over all ranks: eight GPUs got 32768 trials each)."""
+    from polar_amd.montecarlo import next_round
+
+    def rounds(batch, max_err, max_runs, world):
+        done, out = 0, []
+        while done < max_runs:
+            t = next_round(batch, max_err, done, max_runs, world)
+            out.append(t); done += t
+        return out
+
+    assert rounds(0, 100, 1000, 1) == [256, 256, 488]                      # the reference's defaults: 1000 runs, 100 errors
+    assert rounds(0, 100, 3 * 262144, 1)[-2:] == [262144, 262144]
+    r8 = rounds(0, 100, 40 * 262144, 8)
+    assert r8[0] == 256 and max(r8) == 8 * 262144 and r8.count(8 * 262144) >= 3   # every rank reaches 262144 trials per round
+    assert rounds(0, 100, 2000, 3)[0] == 258                               # first round: a multiple of the world size
+    assert rounds(500, 100, 1200, 4) == [500, 500, 200]                    # a fixed batch is the round over ALL ranks
+    assert sum(rounds(0, 7, 12345, 5)) == 12345
