@@ -19,7 +19,8 @@ LIB = os.path.join(HERE, "libpolar_amd.so")
 BUILD = os.path.join(HERE, "_build")
 # (source, extra -D, object tag, extra compiler options): polar_kernels.hip is compiled three times — LLR-domain kernel family,
 # exp-domain kernels of the small groups, exp-domain list of 32 (the headline kernel, with its own scheduler options)
-FLAGS_LIST32 = ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause", "-mllvm", "-amdgpu-use-amdgpu-trackers"]
+FLAGS_LIST32 = ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause", "-mllvm", "-amdgpu-use-amdgpu-trackers"] + \
+               os.environ.get("POLAR_LIST32_FLAGS", "").split()          # (A/B experiments on the list-of-32 translation unit alone)
 SOURCES = [("polar_kernels.hip", ["POLAR_ED_TU=0"], "", []), ("polar_kernels.hip", ["POLAR_ED_TU=1"], ".ed", []),
            ("polar_kernels.hip", ["POLAR_ED_TU=2"], ".ed32", FLAGS_LIST32),
            ("polar_kernels_sc.hip", [], "", []), ("polar_kernels_p1.hip", [], "", []), ("polar_channel.hip", [], "", []),
