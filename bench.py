@@ -84,6 +84,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank != 0:
+        # stdout belongs to rank 0's ONE JSON line: whatever a library of another rank writes there (RCCL prints a version banner
+        # through C stdio, flushed when the process exits — after rank 0's line) goes to stderr instead
+        sys.stdout.flush()
+        os.dup2(2, 1)
     if world != args.gpus:
         raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}: the two must agree "
                          f"(n_gpus in the result line is the number of ranks that really ran)")
@@ -273,8 +278,21 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        sys.stdout.flush()
-        print(json.dumps(res), flush=True)     # the ONE JSON line, last thing on stdout
+        emit_last_line(json.dumps(res))        # the ONE JSON line, last thing on stdout
+
+
+def emit_last_line(line):
+    """Print the result line as the LAST thing this process puts on stdout: C-level buffers first (RCCL's start-up banner sits in
+    one until exit), then the line, then stdout is pointed at stderr so that nothing written later (process-group teardown, exit
+    handlers) can follow it."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(line, flush=True)
+    os.dup2(2, 1)
 
 
 MC_GRID = [1.0, 1.25, 1.5, 1.75, 2.0]        # BASELINE configuration 4: Eb/N0 1:0.25:2 dB, L = 32 + CRC16
@@ -417,10 +435,10 @@ def dry_run(args, world, rank):
             mc["counters_equal_single_gpu_detail"]["native_multi"] = None
     dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"metric": "codewords/s (N=2048 K=1024 L=32 LLR-SCL)", "value": None, "unit": "codewords/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
-                          "runs_all_ranks": int(counters[1]), "scaling": "weak", "monte_carlo": mc,
-                          "config": {"workload": "dry run (gloo, CPU): launcher and counter reduction only"}}), flush=True)
+        emit_last_line(json.dumps({"metric": "codewords/s (N=2048 K=1024 L=32 LLR-SCL)", "value": None, "unit": "codewords/s",
+                                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                                   "runs_all_ranks": int(counters[1]), "scaling": "weak", "monte_carlo": mc,
+                                   "config": {"workload": "dry run (gloo, CPU): launcher and counter reduction only"}}))
 
 
 def traffic_from_profile(args, B):

@@ -38,3 +38,20 @@ def test_n_ranks_on_one_gpu_give_the_single_gpu_counters(built_lib, world):
     assert "error" not in nm, nm
     assert nm["rounds"] == 2 and nm["equals_multiprocess_counters"] is True
     assert nm["block_errors"] == mc["multiprocess"]["block_errors"] and nm["block_errors"][0] > nm["block_errors"][-1] > 0
+
+
+def test_the_result_line_is_the_last_line_on_stdout_with_rccl_initialised(built_lib):
+    """With the RCCL process group up (every N > 1 run; forced here with one rank) RCCL writes a start-up banner through C stdio,
+    which is flushed when the process exits — it used to land AFTER the JSON line, the one thing the driver reads. bench.py flushes
+    the C buffers, prints the line and points stdout at stderr; ranks other than 0 never own stdout at all."""
+    e = dict(os.environ, BENCH_FORCE_DIST="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--batch", "8192",
+                        "--cpu-sample", "0", "--no-other-configs", "--mc-trials", "0"],
+                       capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    line = json.loads(last)                                          # (fails when anything follows the line)
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["bler"]["runs"] == 8192
+    assert sum(1 for l in r.stdout.splitlines() if l.startswith("{")) == 1
