@@ -264,14 +264,16 @@ def main():
     if args.mc_trials > 0:
         del llr, sent
         res["monte_carlo"] = monte_carlo_leg(args, code, dist, dev, rank, world, shared_gpu=shared)
-        llr = torch.empty((B, N), dtype=torch.float64, device=dev)          # (the CPU baseline below re-checks the batch)
-        code.synth_llr_dev(args.seed, trial0, B, s, llr.data_ptr(), 0)
-        torch.cuda.synchronize()
+        if not res["monte_carlo"].get("native_multi_hung"):                 # (else a thread is still inside the handle: hands off)
+            llr = torch.empty((B, N), dtype=torch.float64, device=dev)      # (the CPU baseline below re-checks the batch)
+            code.synth_llr_dev(args.seed, trial0, B, s, llr.data_ptr(), 0)
+            torch.cuda.synchronize()
     if shared:
         res["shared_gpu_test"] = True
-    if rank == 0 and world == 1 and args.cpu_sample != 0:
+    hung = bool(res.get("monte_carlo", {}).get("native_multi_hung"))
+    if rank == 0 and world == 1 and args.cpu_sample != 0 and not hung:
         res["cpu_baseline"] = cpu_baseline(args, code, llr, out)
-    if rank == 0 and world == 1 and not args.no_other_configs:
+    if rank == 0 and world == 1 and not args.no_other_configs and not hung:
         res["other_configs"] = other_configs(args, dev)
         res["one_codeword_per_call"] = latency_record(args, code)
     if dist:
@@ -279,6 +281,8 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         emit_last_line(json.dumps(res))        # the ONE JSON line, last thing on stdout
+        if res.get("monte_carlo", {}).get("native_multi_hung"):
+            os._exit(0)                        # (a thread is still inside the library: no orderly teardown)
 
 
 def emit_last_line(line):
@@ -358,25 +362,41 @@ def monte_carlo_leg(args, code, dist, dev, rank, world, engine=None, native=True
         equal["multiprocess"] = bool(np.array_equal(e_one, e_sh) and np.array_equal(r_one, r_sh))
     # ---- native driver: ONE host process (rank 0) drives all the GPUs of the launch (what the C++ / MATLAB hosts call)
     if rank == 0 and native:
-        try:
-            code.debug_set("multi_timeout_s", 180)
-            devs = list(range(world))
-            if shared_gpu:                                       # one GPU standing in for all of them (separate contexts, host-side sum)
-                code.debug_set("share_device", 1)
-                devs = [0] * world
-            code.get_bler_quick(MC_GRID, Ls, max_runs=min(total, per_round), max_err=no_stop, seed=args.seed, batch=per_round, devices=devs)   # warm-up: contexts, communicators
-            t0 = time.perf_counter()
-            b2, c2 = code.get_bler_quick(MC_GRID, Ls, max_runs=total, max_err=no_stop, seed=args.seed, batch=per_round, devices=devs, return_counters=True)
-            dt2 = time.perf_counter() - t0
-            _, c3 = code.get_bler_quick(MC_GRID, Ls, max_runs=MC_PREFIX, max_err=no_stop, seed=args.seed, batch=MC_PREFIX, devices=devs, return_counters=True)
-            equal["native_multi"] = bool(np.array_equal(e_one, c3["err"]) and np.array_equal(r_one, c3["run"]))
-            out["native_multi"] = {"driver": "polar_get_bler_quick_multi_ex from rank 0: one worker thread, stream and table clone per GPU, "
-                                             "ncclAllReduce(uint64, sum) per round" + ("" if code.last_used_rccl else " (host-side sum: RCCL not used)"),
-                                   "seconds": dt2, "mc_trials_per_s": total / dt2, "rounds": c2["rounds"], "used_rccl": bool(code.last_used_rccl),
-                                   "bler": [float(x) for x in b2[0]], "block_errors": [int(x) for x in c2["err"][0]],
-                                   "equals_multiprocess_counters": bool(np.array_equal(c2["err"], err) and np.array_equal(c2["run"], run))}
-        except Exception as ex:                              # (the headline above must be printed whatever happens here)
-            out["native_multi"] = {"error": str(ex)[:500]}
+        box = {}
+
+        def native_leg():
+            try:
+                code.debug_set("multi_timeout_s", 180)
+                devs = list(range(world))
+                if shared_gpu:                                       # one GPU standing in for all of them (separate contexts, host-side sum)
+                    code.debug_set("share_device", 1)
+                    devs = [0] * world
+                code.get_bler_quick(MC_GRID, Ls, max_runs=min(total, per_round), max_err=no_stop, seed=args.seed, batch=per_round, devices=devs)   # warm-up: contexts, communicators
+                t0 = time.perf_counter()
+                b2, c2 = code.get_bler_quick(MC_GRID, Ls, max_runs=total, max_err=no_stop, seed=args.seed, batch=per_round, devices=devs, return_counters=True)
+                dt2 = time.perf_counter() - t0
+                _, c3 = code.get_bler_quick(MC_GRID, Ls, max_runs=MC_PREFIX, max_err=no_stop, seed=args.seed, batch=MC_PREFIX, devices=devs, return_counters=True)
+                box["equal"] = bool(np.array_equal(e_one, c3["err"]) and np.array_equal(r_one, c3["run"]))
+                box["rec"] = {"driver": "polar_get_bler_quick_multi_ex from rank 0: one worker thread, stream and table clone per GPU, "
+                                        "ncclAllReduce(uint64, sum) per round" + ("" if code.last_used_rccl else " (host-side sum: RCCL not used)"),
+                              "seconds": dt2, "mc_trials_per_s": total / dt2, "rounds": c2["rounds"], "used_rccl": bool(code.last_used_rccl),
+                              "bler": [float(x) for x in b2[0]], "block_errors": [int(x) for x in c2["err"][0]],
+                              "equals_multiprocess_counters": bool(np.array_equal(c2["err"], err) and np.array_equal(c2["run"], run))}
+            except Exception as ex:                              # (the headline above must be printed whatever happens here)
+                box["rec"] = {"error": str(ex)[:500]}
+
+        # in a thread of its own, with a deadline: a communicator set-up that never returns on some node must not take the
+        # headline line with it (the library's own watchdog covers the rounds, not ncclCommInitAll)
+        import threading
+        th = threading.Thread(target=native_leg, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("BENCH_NATIVE_DEADLINE_S", "420")))
+        if th.is_alive():
+            out["native_multi"] = {"error": "the native multi-device leg did not finish before its deadline; skipped"}
+            out["native_multi_hung"] = True
+        else:
+            out["native_multi"] = box.get("rec", {"error": "no record"})
+            equal["native_multi"] = box.get("equal")
     hbar()
     out["counters_equal_single_gpu"] = (None if not native else bool(equal["multiprocess"] and (equal["native_multi"] is not False)))
     out["counters_equal_single_gpu_detail"] = dict(equal, prefix_trials=MC_PREFIX)

@@ -55,3 +55,22 @@ def test_the_result_line_is_the_last_line_on_stdout_with_rccl_initialised(built_
     line = json.loads(last)                                          # (fails when anything follows the line)
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["bler"]["runs"] == 8192
     assert sum(1 for l in r.stdout.splitlines() if l.startswith("{")) == 1
+
+
+def test_a_native_leg_that_does_not_return_cannot_take_the_result_line_with_it(built_lib):
+    """The single-process multi-GPU leg of the Monte-Carlo record runs in a thread of its own with a deadline (the library's watchdog
+    covers the rounds, not a communicator set-up that never returns on some node): with the deadline set to (almost) nothing the
+    launch still ends with rc 0 and ONE result line — headline, multi-process record and an error entry in place of the native one."""
+    world = 2
+    e = dict(os.environ, BENCH_NATIVE_DEADLINE_S="0.001")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--shared-gpu-gloo", "--steps", "1",
+                        "--warmup", "1", "--batch", "4096", "--mc-trials", str(262144 * world)],
+                       capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    mc = line["monte_carlo"]
+    assert line["n_gpus"] == world and line["value"] > 0
+    assert "deadline" in mc["native_multi"]["error"] and mc["native_multi_hung"] is True
+    assert mc["counters_equal_single_gpu_detail"]["multiprocess"] is True and mc["multiprocess"]["rounds"] == 1
