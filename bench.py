@@ -276,6 +276,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_other_configs and not hung:
         res["other_configs"] = other_configs(args, dev)
         res["one_codeword_per_call"] = latency_record(args, code)
+        res["host_batch"] = host_batch_record(args, dev)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -651,6 +652,99 @@ def run_config(name, args, dev, steps=3, with_cpu=True):
                                "gpu_vs_cpu_mismatching_codewords": int((ref_out != out[:cpu_n].cpu().numpy()).any(axis=1).sum())}
     del llr, sent, out
     return res
+
+
+HOST_BATCH_CONFIGS = ("config2", "config3", "config5", "headline")
+HOST_KNOBS = ("host_pipe_min_bytes", "host_chunk_bytes", "host_lanes", "host_threads")
+
+
+def pcie_rates(dev, mib=256):
+    """Pinned H2D / D2H rate of the link (GB/s) measured live, what a pageable hipMemcpy of the same size reaches, and one
+    core's memcpy into pinned memory (what a staging loop is made of)."""
+    n = mib << 20
+    pin = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+    pin.fill_(1)
+    d = torch.empty(n, dtype=torch.uint8, device=dev)
+    page = np.ones(n, np.uint8)
+    out = {"bytes": n}
+    for name, fn in (("pinned_h2d", lambda: d.copy_(pin, non_blocking=True)), ("pinned_d2h", lambda: pin.copy_(d, non_blocking=True)),
+                     ("pageable_h2d", lambda: d.copy_(torch.from_numpy(page)))):
+        fn(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            t = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
+        out[name + "_GBps"] = n / min(ts) / 1e9
+    view = pin.numpy()
+    t = time.perf_counter(); view[:] = page; out["memcpy_to_pinned_one_core_GBps"] = n / (time.perf_counter() - t) / 1e9
+    return out
+
+
+def host_batch_config(name, B, dev, pcie, settings=(("default", {}),), reps=3, seed=7):
+    """One configuration through the HOST-POINTER batch entry points (polar_decode_scl_llr_batch / _f32 — the only path a MEX or
+    PolarCode.hpp caller has: PolarCode.cpp:130-148, PolarM/PolarCode.m:312-322) from PAGEABLE numpy memory: codewords/s
+    including staging, H2D, decode, D2H, next to the device-resident rate of the same batch and the bound
+    min(device-resident rate, pinned PCIe rate / input bytes per codeword); bits compared with the device-resident decode."""
+    import ctypes as C
+    import polar_amd
+    if name == "headline":
+        n, K, crc, L, axis, const = 11, 1024, 16, 32, 2.0, "bpsk"
+        C.CDLL(None).srand(C.c_uint(1))
+        code = polar_amd.PolarCode(n, K, 0.32, crc)
+    else:
+        n, K, crc, L, _, axis, const, _, _ = OTHER_CONFIGS[name]
+        code = make_config(name)
+    N = 1 << n
+    llr_d = torch.empty((B, N), dtype=torch.float64, device=dev)
+    out_d = torch.empty((B, K), dtype=torch.uint8, device=dev)
+    if const == "bpsk":
+        code.synth_llr_dev(seed, 0, B, code.snr_sqrt_linear(axis), llr_d.data_ptr())
+    else:
+        code.synth_bicm_llr_dev(const, seed, 0, B, axis, llr_d.data_ptr())
+
+    def timed(fn):
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter(); fn(); ts.append(time.perf_counter() - t)
+        return min(ts), float(np.median(ts))
+
+    def dev_step():
+        code.decode_scl_llr_dev(llr_d.data_ptr(), B, L, out_d.data_ptr()); torch.cuda.synchronize()
+    dev_step()
+    dmin, _ = timed(dev_step)
+    want = out_d.cpu().numpy()
+    llr64 = llr_d.cpu().numpy()                       # pageable host memory, as a caller's array is
+    llr32 = llr64.astype(np.float32)
+    l32_d = torch.from_numpy(llr32).to(dev)           # (float rows are another input: their own device-resident decode is the expectation)
+    code.decode_scl_llr_dev_f32(l32_d.data_ptr(), B, L, out_d.data_ptr()); torch.cuda.synchronize()
+    want32 = out_d.cpu().numpy()
+    del llr_d, l32_d, out_d
+    rec = {"config": name, "workload": f"N={N} K={K} crc={crc} L={L} {const}, batch {B}, LLRs in pageable host memory",
+           "batch": B, "device_resident_cw_per_s": B / dmin, "rows": []}
+    for label, kn in settings:
+        for k in HOST_KNOBS:
+            code.debug_set(k, kn.get(k, 0))
+        for dt_name, a, w in (("f64", llr64, want), ("f32", llr32, want32)):
+            got = code.decode_scl_llr(a, L)           # warm-up: staging slots, second lane
+            ok = bool((got == w).all())
+            tmin, tmed = timed(lambda: code.decode_scl_llr(a, L))
+            pcie_bound = pcie["pinned_h2d_GBps"] * 1e9 / (N * a.itemsize)
+            bound = min(B / dmin, pcie_bound)
+            rec["rows"].append({"setting": label, "llr": dt_name, "value": B / tmin, "unit": "codewords/s", "median": B / tmed, "ms": tmin * 1e3,
+                                "input_GBps": B * N * a.itemsize / tmin / 1e9, "pcie_bound_cw_per_s": pcie_bound,
+                                "bound_cw_per_s": bound, "bound_by": "device" if B / dmin < pcie_bound else "pcie", "frac_of_bound": B / tmin / bound,
+                                "bits_equal_device_resident": ok, "chunks": code.debug_get("host_chunks"),
+                                "chunk_codewords": code.debug_get("host_chunk_cw"), "lanes": code.debug_get("host_lanes"),
+                                "copy_threads": code.debug_get("host_threads")})
+    for k in HOST_KNOBS:
+        code.debug_set(k, 0)
+    code.close()
+    return rec
+
+
+def host_batch_record(args, dev):
+    pcie = pcie_rates(dev)
+    return {"abi": "polar_decode_scl_llr_batch / polar_decode_scl_llr_batch_f32 (host pointers: staging + H2D + decode + D2H inside the call)",
+            "pcie": pcie, "configs": [host_batch_config(c, 65536, dev, pcie) for c in HOST_BATCH_CONFIGS]}
 
 
 def latency_record(args, code):

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
@@ -70,7 +71,90 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// Host cores this process may use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes report 256 logical
+// CPUs and run the container on a 16-CPU quota).
+int usable_cpus() {
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32]; long per = 0;
+        if (fscanf(f, "%31s %ld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) n = std::min<long>(n, std::max<long>(1, atol(q) / per));
+        fclose(f);
+    }
+    return std::max(1, n);
+}
+
+// Copies between the caller's pageable memory and the pinned staging slots of the host-pointer decode path, spread
+// over a few parked threads: one core moves ~10 GB/s, the PCIe link ~55 GB/s.
+struct CopyPool {
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    unsigned gen = 0;
+    bool quit = false;
+    char *dst = nullptr; const char *src = nullptr; size_t bytes = 0;
+    std::atomic<size_t> next{0};
+    int pending = 0;
+    static constexpr size_t kSlice = (size_t)2 << 20;
+    void work() {
+        for (;;) {
+            const size_t off = next.fetch_add(kSlice);
+            if (off >= bytes) return;
+            memcpy(dst + off, src + off, std::min(kSlice, bytes - off));
+        }
+    }
+    void start(int n) {
+        for (int i = 0; i < n; ++i)
+            threads.emplace_back([this] {
+                unsigned seen = 0;
+                for (;;) {
+                    {
+                        std::unique_lock<std::mutex> lk(m);
+                        cv_job.wait(lk, [&] { return quit || gen != seen; });
+                        if (quit) return;
+                        seen = gen;
+                    }
+                    work();
+                    std::lock_guard<std::mutex> lk(m);
+                    if (--pending == 0) cv_done.notify_all();
+                }
+            });
+    }
+    void copy(void *d, const void *s, size_t n) {          // (the calling thread takes its share)
+        if (threads.empty() || n < 4 * kSlice) { memcpy(d, s, n); return; }
+        {
+            std::lock_guard<std::mutex> lk(m);
+            dst = (char *)d; src = (const char *)s; bytes = n; next = 0; pending = (int)threads.size(); ++gen;
+        }
+        cv_job.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    ~CopyPool() {
+        { std::lock_guard<std::mutex> lk(m); quit = true; }
+        cv_job.notify_all();
+        for (auto &t : threads) t.join();
+    }
+};
+
 }  // namespace
+
+// The pipelined host-pointer decode path (host_decode): a ring of pinned staging slots and device slots, one copy stream,
+// two decode lanes (the handle itself and a private copy of its tables with its own scratch) on their own streams.
+struct HostPipe {
+    static constexpr int R = 4;
+    hipStream_t copy = nullptr, lane[2] = {nullptr, nullptr};
+    hipEvent_t h2d[R] = {}, done[R] = {};
+    void *pin_in[R] = {}; uint8_t *pin_out[R] = {};
+    void *d_in[R] = {}; uint8_t *d_out[R] = {};
+    size_t in_cap = 0, out_cap = 0;          // bytes per slot
+    polar_code *ctx1 = nullptr;              // the second lane's context (owned; dropped with the clones by every setter)
+    std::unique_ptr<CopyPool> pool;
+    // what the last pipelined call did (polar_debug_get "host_chunks", "host_chunk_cw", "host_lanes", "host_threads")
+    long last_chunks = 0, last_chunk_cw = 0, last_lanes = 0, last_threads = 0;
+};
 
 struct polar_code {
     int n = 0, N = 0, K = 0, crc = 0;
@@ -126,6 +210,11 @@ struct polar_code {
         int fail_collective = -1;    // (test hook) this worker's collective enqueue "fails" in its second round (after the barrier)
         long multi_timeout_s = 1800; // watchdog of a multi-device round: communicators are aborted when a round takes longer
         long lat_max_b = 0;          // batches up to this size take the one-codeword-per-wave kernels (0 = default, -1 = never)
+        // the pipelined host-pointer path (host_decode): 0 = default everywhere
+        long host_pipe_min_bytes = 0;  // input bytes from which a host-pointer batch is pipelined (-1 = never: one copy in, decode, one copy out)
+        long host_chunk_bytes = 0;     // input bytes per chunk / staging slot
+        long host_lanes = 0;           // decode lanes (1 or 2)
+        long host_threads = 0;         // threads that copy between the caller's memory and the pinned slots (calling thread included)
     } knobs;
     // Monte-Carlo engine (device side): alive lists (double-buffered), their lengths, per-round counters
     DevBuf<uint64_t> d_alive[2];
@@ -141,6 +230,7 @@ struct polar_code {
     uint8_t *pin_out = nullptr, *pin_out_dev = nullptr; // decoded bits [B][K] followed by one flag byte per codeword
     size_t pin_in_cap = 0, pin_out_cap = 0;
     uint8_t *lat_flag_bytes = nullptr;                  // (set around a decode_impl call by host_decode)
+    struct HostPipe *hpipe = nullptr;                   // pipelined staging of the large host-pointer batches (host_decode)
     // statistics of the last get_bler_quick* call (polar_debug_get)
     long last_rounds = 0, last_round_max_per_device = 0, worker_threads_started = 0;
     // tuning
@@ -389,6 +479,7 @@ int read_env_knobs(polar_code *h) {
 }
 
 void multi_release(polar_code *h, bool abort_comms);     // (defined next to bler_impl)
+polar_code *copy_ctx(polar_code *h, int dev);            // (defined next to clone_on_device)
 
 }  // namespace
 
@@ -462,11 +553,14 @@ int polar_create_explicit(int n, int K, int crc, const uint8_t *frozen, const ui
     return POLAR_OK;
 }
 
+static void hostpipe_release(polar_code_t *h);      // (defined with host_decode)
+
 void polar_destroy(polar_code_t *h) {
     if (!h) return;
     multi_release(h, false);
     for (polar_code *c : h->clones) polar_destroy(c);
     h->clones.clear();
+    hostpipe_release(h);
     DevGuard dg_;
     {
         int cur = -1;
@@ -515,6 +609,7 @@ int polar_get_crc_matrix(const polar_code_t *h, uint8_t *m) {
 static void drop_clones(polar_code_t *h) {
     for (polar_code *c : h->clones) polar_destroy(c);
     h->clones.clear();
+    if (h->hpipe && h->hpipe->ctx1) { polar_destroy(h->hpipe->ctx1); h->hpipe->ctx1 = nullptr; }   // (the second decode lane of host_decode)
 }
 
 // test hook: number of unfrozen leaves derive_tables() marked as weak (see there)
@@ -537,6 +632,10 @@ int polar_debug_set(polar_code_t *h, const char *key, long value) {
     else if (s == "fail_device") k.fail_device = (int)value;
     else if (s == "fail_collective") k.fail_collective = (int)value;
     else if (s == "lat_max_b") k.lat_max_b = value;
+    else if (s == "host_pipe_min_bytes") k.host_pipe_min_bytes = value;
+    else if (s == "host_chunk_bytes") k.host_chunk_bytes = value;
+    else if (s == "host_lanes") { if (value < 0 || value > 2) return fail(POLAR_E_ARG, "host_lanes must be 0 (default), 1 or 2"); k.host_lanes = value; }
+    else if (s == "host_threads") { if (value < 0) return fail(POLAR_E_ARG, "host_threads must be >= 0"); k.host_threads = value; }
     else if (s == "multi_timeout_s") { if (value < 0) return fail(POLAR_E_ARG, "multi_timeout_s must be >= 0 (0 = no watchdog)"); k.multi_timeout_s = value; }
     else return fail(POLAR_E_ARG, "polar_debug_set: unknown key '%s'", key);
     drop_clones(h);          // (the per-device contexts carry a copy of the knobs)
@@ -555,6 +654,10 @@ long polar_debug_get(const polar_code_t *h, const char *key) {
     if (s == "last_rounds") return h->last_rounds;
     if (s == "last_round_max_per_device") return h->last_round_max_per_device;
     if (s == "worker_threads_started") return h->worker_threads_started;
+    if (s == "host_chunks") return h->hpipe ? h->hpipe->last_chunks : 0;
+    if (s == "host_chunk_cw") return h->hpipe ? h->hpipe->last_chunk_cw : 0;
+    if (s == "host_lanes") return h->hpipe ? h->hpipe->last_lanes : 0;
+    if (s == "host_threads") return h->hpipe ? h->hpipe->last_threads : 0;
     return -1;
 }
 
@@ -832,6 +935,127 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
 // reads and writes directly (no DMA copies: a 16-KB hipMemcpy costs more than moving the bytes), the flags come back with
 // the bits, and the work list + general kernel over the flagged codewords (normally none) are launched only when a flag is
 // set — the device-resident entry points, which must not wait, always launch them.
+//
+// LARGE batches are pipelined (round 5): the batch is cut into chunks of ~64 MiB of LLRs; chunk k is copied by a few host
+// threads from the caller's pageable memory into a pinned slot (a pageable hipMemcpy is a single-threaded staging loop
+// inside the runtime: a fraction of the link), moved by the copy engine on a copy stream, decoded on one of TWO decode
+// lanes — the handle and a private copy of its tables with its own scratch, each on its own stream: the persistent waves of
+// chunk k + 1 take the slots chunk k's waves leave, so a launch's tail overlaps the next launch's head instead of idling
+// the device once per chunk — and its bits come back through a pinned slot: H2D(k + 1) || decode(k) || D2H(k - 1).
+static void hostpipe_release(polar_code_t *h) {
+    HostPipe *hp = h->hpipe;
+    if (!hp) return;
+    h->hpipe = nullptr;
+    if (hp->ctx1) polar_destroy(hp->ctx1);
+    for (int i = 0; i < HostPipe::R; ++i) {
+        if (hp->pin_in[i]) (void)hipHostFree(hp->pin_in[i]);
+        if (hp->pin_out[i]) (void)hipHostFree(hp->pin_out[i]);
+        if (hp->d_in[i]) (void)hipFree(hp->d_in[i]);
+        if (hp->d_out[i]) (void)hipFree(hp->d_out[i]);
+        if (hp->h2d[i]) (void)hipEventDestroy(hp->h2d[i]);
+        if (hp->done[i]) (void)hipEventDestroy(hp->done[i]);
+    }
+    if (hp->copy) (void)hipStreamDestroy(hp->copy);
+    for (hipStream_t s : hp->lane) if (s) (void)hipStreamDestroy(s);
+    delete hp;
+}
+
+static int hostpipe_ensure(polar_code_t *h, size_t in_slot, size_t out_slot, int lanes, int threads) {
+    if (!h->hpipe) h->hpipe = new HostPipe;
+    HostPipe *hp = h->hpipe;
+    if (!hp->copy) HIP_TRY(hipStreamCreateWithFlags(&hp->copy, hipStreamNonBlocking));
+    for (int l = 0; l < 2; ++l) if (!hp->lane[l]) HIP_TRY(hipStreamCreateWithFlags(&hp->lane[l], hipStreamNonBlocking));
+    for (int i = 0; i < HostPipe::R; ++i) {
+        if (!hp->h2d[i]) HIP_TRY(hipEventCreateWithFlags(&hp->h2d[i], hipEventDisableTiming));
+        if (!hp->done[i]) HIP_TRY(hipEventCreateWithFlags(&hp->done[i], hipEventDisableTiming));
+    }
+    if (hp->in_cap < in_slot) {
+        for (int i = 0; i < HostPipe::R; ++i) {
+            if (hp->pin_in[i]) (void)hipHostFree(hp->pin_in[i]);
+            if (hp->d_in[i]) (void)hipFree(hp->d_in[i]);
+            hp->pin_in[i] = nullptr; hp->d_in[i] = nullptr;
+        }
+        hp->in_cap = 0;
+        for (int i = 0; i < HostPipe::R; ++i) {
+            HIP_TRY(hipHostMalloc(&hp->pin_in[i], in_slot, hipHostMallocDefault));
+            ++g_allocs;
+            HIP_TRY(hipMalloc(&hp->d_in[i], in_slot));
+        }
+        hp->in_cap = in_slot;
+    }
+    if (hp->out_cap < out_slot) {
+        for (int i = 0; i < HostPipe::R; ++i) {
+            if (hp->pin_out[i]) (void)hipHostFree(hp->pin_out[i]);
+            if (hp->d_out[i]) (void)hipFree(hp->d_out[i]);
+            hp->pin_out[i] = nullptr; hp->d_out[i] = nullptr;
+        }
+        hp->out_cap = 0;
+        for (int i = 0; i < HostPipe::R; ++i) {
+            HIP_TRY(hipHostMalloc((void **)&hp->pin_out[i], out_slot, hipHostMallocDefault));
+            ++g_allocs;
+            HIP_TRY(hipMalloc((void **)&hp->d_out[i], out_slot));
+        }
+        hp->out_cap = out_slot;
+    }
+    if (lanes > 1 && !hp->ctx1) {
+        hp->ctx1 = copy_ctx(h, h->device);
+        DevGuard g2;
+        int rc = ensure_device(hp->ctx1, g2);
+        g2.prev = -1;
+        if (rc) return rc;
+    }
+    if (!hp->pool || (int)hp->pool->threads.size() != threads - 1) {
+        hp->pool.reset(new CopyPool);
+        hp->pool->start(threads - 1);
+    }
+    return POLAR_OK;
+}
+
+static int host_decode_pipelined(polar_code_t *h, const void *llr, int llr_f32, long B, int L, uint8_t *out, long chunk_cw, int lanes, int threads) {
+    const size_t esz = llr_f32 ? sizeof(float) : sizeof(double);
+    const size_t row_in = (size_t)h->N * esz, row_out = (size_t)h->K;
+    // equal chunks (a short last chunk would take another kernel family and its first-use allocations in mid-pipeline)
+    const long n_chunks = (B + chunk_cw - 1) / chunk_cw;
+    const long C = (((B + n_chunks - 1) / n_chunks) + 7) / 8 * 8;
+    int rc = hostpipe_ensure(h, (size_t)C * row_in, (size_t)C * row_out, lanes, threads);
+    if (rc) return rc;
+    HostPipe *hp = h->hpipe;
+    hp->last_chunks = n_chunks; hp->last_chunk_cw = C; hp->last_lanes = lanes; hp->last_threads = threads;
+    // (the handle's scratch may still be in use by work the caller put on the null stream through this handle)
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    constexpr int R = HostPipe::R;
+    auto drain = [&] { (void)hipStreamSynchronize(hp->copy); for (hipStream_t s : hp->lane) (void)hipStreamSynchronize(s); };
+    auto finish = [&](long j) -> int {                      // chunk j: wait for its bits, hand them to the caller
+        const int slot = (int)(j % R);
+        const long b0 = j * C, nb = std::min(C, B - b0);
+        hipError_t e = hipEventSynchronize(hp->done[slot]);
+        if (e != hipSuccess) return fail(POLAR_E_DEVICE, "host pipeline: chunk %ld failed: %s", j, hipGetErrorString(e));
+        hp->pool->copy(out + (size_t)b0 * row_out, hp->pin_out[slot], (size_t)nb * row_out);
+        return POLAR_OK;
+    };
+    long k = 0;
+    for (; k < n_chunks && !rc; ++k) {
+        const int slot = (int)(k % R);
+        const long b0 = k * C, nb = std::min(C, B - b0);
+        if (k >= R && (rc = finish(k - R))) break;          // (frees the slot: its H2D, decode and D2H are all behind `done`)
+        hp->pool->copy(hp->pin_in[slot], (const char *)llr + (size_t)b0 * row_in, (size_t)nb * row_in);
+        hipError_t e = hipMemcpyAsync(hp->d_in[slot], hp->pin_in[slot], (size_t)nb * row_in, hipMemcpyHostToDevice, hp->copy);
+        if (e == hipSuccess) e = hipEventRecord(hp->h2d[slot], hp->copy);
+        const int l = (int)(k % lanes);
+        hipStream_t st = hp->lane[l];
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, hp->h2d[slot], 0);
+        if (e != hipSuccess) { rc = fail(POLAR_E_DEVICE, "host pipeline: copy of chunk %ld: %s", k, hipGetErrorString(e)); break; }
+        if ((rc = decode_impl(l ? hp->ctx1 : h, hp->d_in[slot], llr_f32, nb, nullptr, L, hp->d_out[slot], nullptr, st, nullptr, nullptr))) break;
+        e = hipMemcpyAsync(hp->pin_out[slot], hp->d_out[slot], (size_t)nb * row_out, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipEventRecord(hp->done[slot], st);
+        if (e != hipSuccess) { rc = fail(POLAR_E_DEVICE, "host pipeline: result copy of chunk %ld: %s", k, hipGetErrorString(e)); break; }
+    }
+    if (rc) { const std::string msg = g_err; drain(); g_err = msg; return rc; }
+    for (long j = std::max<long>(0, n_chunks - R); j < n_chunks; ++j)
+        if ((rc = finish(j))) { const std::string msg = g_err; drain(); g_err = msg; return rc; }
+    return POLAR_OK;
+}
+
 static int host_decode(polar_code_t *h, const void *llr, int llr_f32, long B, int L, uint8_t *out) {
     if (!h || !llr || !out) return fail(POLAR_E_ARG, "NULL argument");
     if (L < 1 || L > POLAR_MAX_LIST) return fail(POLAR_E_ARG, "list size %d out of range [1, %d]", L, POLAR_MAX_LIST);
@@ -843,6 +1067,21 @@ static int host_decode(polar_code_t *h, const void *llr, int llr_f32, long B, in
     const size_t esz = llr_f32 ? sizeof(float) : sizeof(double);
     const size_t in_bytes = (size_t)B * h->N * esz, out_bytes = (size_t)B * h->K;
     const int mode = h->knobs.mode_override >= 0 ? h->knobs.mode_override : h->mode;
+    if (h->hpipe) h->hpipe->last_chunks = 0;
+    {
+        const polar_code::Knobs &kn = h->knobs;
+        const size_t min_bytes = kn.host_pipe_min_bytes > 0 ? (size_t)kn.host_pipe_min_bytes : (size_t)32 << 20;
+        if (kn.host_pipe_min_bytes >= 0 && in_bytes >= min_bytes) {
+            // chunks of 64 MiB of LLRs (4096 codewords of N = 2048 in doubles: half of what the list-of-32 kernel holds at a
+            // time, so that two lanes keep the device full), at least four chunks per batch
+            size_t cb = kn.host_chunk_bytes > 0 ? (size_t)kn.host_chunk_bytes : (size_t)64 << 20;
+            if (kn.host_chunk_bytes <= 0) cb = std::min(cb, std::max<size_t>(in_bytes / 4, (size_t)8 << 20));
+            const long chunk_cw = std::max<long>(8, (long)(cb / ((size_t)h->N * esz)) / 8 * 8);
+            const int lanes = kn.host_lanes == 1 ? 1 : 2;
+            const int threads = kn.host_threads > 0 ? (int)std::min<long>(kn.host_threads, 64) : std::max(1, std::min(8, usable_cpus() / 2));
+            if (B > chunk_cw) return host_decode_pipelined(h, llr, llr_f32, B, L, out, chunk_cw, lanes, threads);
+        }
+    }
     if (L == 1 && mode != 1 && use_sc_lat(h, B) && B <= 64) {
         if (h->pin_in_cap < in_bytes) {
             if (h->pin_in) (void)hipHostFree(h->pin_in);
@@ -1396,6 +1635,12 @@ polar_code *clone_on_device(polar_code *h, int dev, bool fresh = false) {
         if (dev == h->device) return h;
         for (polar_code *c : h->clones) if (c->device == dev) return c;
     }
+    polar_code *c = copy_ctx(h, dev);
+    h->clones.push_back(c);
+    return c;
+}
+// a copy of the handle's tables and settings bound to `dev`, with its own (not yet allocated) device state; the caller owns it
+polar_code *copy_ctx(polar_code *h, int dev) {
     polar_code *c = new polar_code;
     c->n = h->n; c->N = h->N; c->K = h->K; c->crc = h->crc; c->eps = h->eps;
     c->frozen = h->frozen; c->order = h->order; c->bitrev = h->bitrev; c->crcm = h->crcm;
@@ -1404,7 +1649,6 @@ polar_code *clone_on_device(polar_code *h, int dev, bool fresh = false) {
     c->device = dev;
     c->waves_per_cu = h->waves_per_cu; c->lds_log = h->lds_log; c->pipe = h->pipe; c->prefix_on = h->prefix_on; c->mode = h->mode;
     c->knobs = h->knobs;
-    h->clones.push_back(c);
     return c;
 }
 

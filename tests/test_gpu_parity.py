@@ -87,6 +87,73 @@ def test_ragged_batches_and_empty(built_lib, oracle_built):
     assert (g.decode_scl_llr(llr[5], 8) == want[5]).all()
 
 
+@pytest.mark.parametrize("L", [1, 2, 4, 32])
+def test_pipelined_host_batches_at_chunk_boundaries(built_lib, oracle_built, L):
+    """Large host-pointer batches are cut into chunks (pinned staging, copy stream, two decode lanes: polar_host.cpp
+    host_decode_pipelined). Forced here on small batches with tiny chunks: a batch that is one codeword short of / exactly /
+    one codeword over a whole number of chunks, fewer chunks than ring slots and many more, one lane and two, doubles and
+    floats — every row must be what the unpipelined path returns (== the oracle), in its place."""
+    o, g = _pair(8, 128, 4)
+    llr, _ = o.synth_llr(11, 0, 1000, o.snr_sqrt_linear(1.5))
+    want = o.decode_scl_llr(llr, L)
+    row = 256 * 8
+    g.debug_set("host_pipe_min_bytes", 1)
+    for lanes in (1, 2):
+        g.debug_set("host_lanes", lanes)
+        for chunk_cw, Bs in ((8, (9, 15, 16, 17, 31, 33, 100)), (64, (65, 127, 128, 129, 448, 1000)), (200, (201, 799, 1000))):
+            g.debug_set("host_chunk_bytes", chunk_cw * row)
+            for B in Bs:
+                got = g.decode_scl_llr(llr[:B], L)
+                assert g.debug_get("host_chunks") == -(-B // chunk_cw), (B, chunk_cw, g.debug_get("host_chunks"))
+                assert g.debug_get("host_lanes") == lanes
+                assert (got == want[:B]).all(), (L, lanes, chunk_cw, B)
+    # floats: half the bytes per row, the chunk is then twice the codewords
+    g.debug_set("host_chunk_bytes", 64 * row)
+    l32 = llr.astype(np.float32)
+    want32 = o.decode_scl_llr(l32.astype(np.float64), L)
+    got = g.decode_scl_llr(l32[:777], L)
+    assert g.debug_get("host_chunks") == -(-777 // 128) and (got == want32[:777]).all()
+    # a batch that fits one chunk is not pipelined; and the knob -1 switches the pipeline off whatever the size
+    got = g.decode_scl_llr(llr[:64], L)
+    assert g.debug_get("host_chunks") == 0 and (got == want[:64]).all()
+    g.debug_set("host_pipe_min_bytes", -1)
+    got = g.decode_scl_llr(llr, L)
+    assert g.debug_get("host_chunks") == 0 and (got == want).all()
+    # a setter between two pipelined calls drops the second lane's copy of the tables: the next call rebuilds it
+    g.debug_set("host_pipe_min_bytes", 1)
+    g.debug_set("host_lanes", 2)
+    g.set_mode(1)
+    assert (g.decode_scl_llr(llr, L) == want).all() and g.debug_get("host_chunks") == -(-1000 // 64)
+    g.set_mode(0)
+    assert (g.decode_scl_llr(llr, L) == want).all()
+
+
+def test_pipelined_host_batch_at_the_default_settings(built_lib):
+    """The defaults (no knob): 16 384 codewords of the headline code at list size 1 (256 MiB of doubles: four chunks of 64 MiB)
+    through the host-pointer entry point == the device-resident decode of the same rows; a CRC matrix set in between
+    reaches both decode lanes."""
+    import ctypes as C
+    import torch
+    C.CDLL(None).srand(C.c_uint(1))
+    g = polar_amd.PolarCode(11, 1024, 0.32, 16)
+    B = 16384
+    d_llr = torch.empty((B, 2048), dtype=torch.float64, device="cuda")
+    d_out = torch.empty((B, 1024), dtype=torch.uint8, device="cuda")
+    g.synth_llr_dev(5, 0, B, g.snr_sqrt_linear(2.0), d_llr.data_ptr())
+    llr = d_llr.cpu().numpy()
+    for L in (1, 4):
+        g.decode_scl_llr_dev(d_llr.data_ptr(), B, L, d_out.data_ptr())
+        torch.cuda.synchronize()
+        got = g.decode_scl_llr(llr, L)
+        assert g.debug_get("host_chunks") == 4 and g.debug_get("host_lanes") == 2
+        assert (got == d_out.cpu().numpy()).all()
+    m = g.crc_matrix
+    g.crc_matrix = m[::-1].copy()
+    g.decode_scl_llr_dev(d_llr.data_ptr(), B, 4, d_out.data_ptr())
+    torch.cuda.synchronize()
+    assert (g.decode_scl_llr(llr, 4) == d_out.cpu().numpy()).all()
+
+
 @pytest.mark.parametrize("lds_log", [3, 4, 5])
 def test_tuning_knobs_do_not_change_results(built_lib, oracle_built, lds_log):
     o, g = _pair(11, 1024, 16)
