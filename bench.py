@@ -655,7 +655,7 @@ def run_config(name, args, dev, steps=3, with_cpu=True):
 
 
 HOST_BATCH_CONFIGS = ("config2", "config3", "config5", "headline")
-HOST_KNOBS = ("host_pipe_min_bytes", "host_chunk_bytes", "host_lanes", "host_threads")
+HOST_KNOBS = ("host_pipe_min_bytes", "host_chunk_bytes", "host_lanes", "host_threads", "host_ramp")
 
 
 def pcie_rates(dev, mib=256):
@@ -724,14 +724,20 @@ def host_batch_config(name, B, dev, pcie, settings=(("default", {}),), reps=3, s
         for k in HOST_KNOBS:
             code.debug_set(k, kn.get(k, 0))
         for dt_name, a, w in (("f64", llr64, want), ("f32", llr32, want32)):
-            got = code.decode_scl_llr(a, L)           # warm-up: staging slots, second lane
+            got = code.decode_scl_llr(a, L)           # warm-up: staging slots, decode lanes (and a FRESH output array)
             ok = bool((got == w).all())
-            tmin, tmed = timed(lambda: code.decode_scl_llr(a, L))
+            # the caller keeps its output array from call to call (a fresh one costs 16 384 page faults per 64 MiB on every
+            # call, whoever writes it); "fresh_out" below is the rate with a new array per call, as a MEX gateway returns it
+            tmin, tmed = timed(lambda: code.decode_scl_llr(a, L, out=got))
+            ok = ok and bool((got == w).all())
+            tfresh, _ = timed(lambda: code.decode_scl_llr(a, L))
             pcie_bound = pcie["pinned_h2d_GBps"] * 1e9 / (N * a.itemsize)
             bound = min(B / dmin, pcie_bound)
             rec["rows"].append({"setting": label, "llr": dt_name, "value": B / tmin, "unit": "codewords/s", "median": B / tmed, "ms": tmin * 1e3,
                                 "input_GBps": B * N * a.itemsize / tmin / 1e9, "pcie_bound_cw_per_s": pcie_bound,
                                 "bound_cw_per_s": bound, "bound_by": "device" if B / dmin < pcie_bound else "pcie", "frac_of_bound": B / tmin / bound,
+                                "fresh_out_value": B / tfresh,
+                                "host_thread_us": {k: code.debug_get("host_us_" + k) for k in ("copy_in", "wait", "copy_out", "total")},
                                 "bits_equal_device_resident": ok, "chunks": code.debug_get("host_chunks"),
                                 "chunk_codewords": code.debug_get("host_chunk_cw"), "lanes": code.debug_get("host_lanes"),
                                 "copy_threads": code.debug_get("host_threads")})

@@ -286,23 +286,25 @@ class PolarCode:
         return out[0] if single else out
 
     # ---- decoders -----------------------------------------------------------------------
-    def decode_scl_llr(self, llr, list_size):
+    def decode_scl_llr(self, llr, list_size, out=None):
         """PolarCode::decode_scl_llr (PolarCode.cpp:130-148). `llr` is [N] or [B, N]; float32 arrays
-        travel as float32 and are widened exactly on the device, anything else is taken as float64."""
-        if isinstance(llr, np.ndarray) and llr.dtype == np.float32:
-            a = np.ascontiguousarray(llr)
-            single = a.ndim == 1
-            a2 = a.reshape(-1, self.N)
-            out = np.zeros((a2.shape[0], self.K), np.uint8)
-            _check(lib().polar_decode_scl_llr_batch_f32(self._h, _p(a2, C.POINTER(C.c_float)), C.c_long(a2.shape[0]),
-                                                        C.c_int(list_size), _p(out, _u8p)))
-            return out[0] if single else out
-        a = np.ascontiguousarray(llr, np.float64)
+        travel as float32 and are widened exactly on the device, anything else is taken as float64.
+        out (optional): a C-contiguous uint8 [B, K] array to receive the bits (a caller that decodes batch after batch keeps
+        one: a fresh 64-MiB array costs its page faults on every call)."""
+        f32 = isinstance(llr, np.ndarray) and llr.dtype == np.float32
+        a = np.ascontiguousarray(llr) if f32 else np.ascontiguousarray(llr, np.float64)
         single = a.ndim == 1
         a2 = a.reshape(-1, self.N)
-        out = np.zeros((a2.shape[0], self.K), np.uint8)
-        _check(lib().polar_decode_scl_llr_batch(self._h, _p(a2, _dp), C.c_long(a2.shape[0]), C.c_int(list_size),
-                                                _p(out, _u8p)))
+        if out is None:
+            out = np.zeros((a2.shape[0], self.K), np.uint8)
+        elif out.dtype != np.uint8 or out.shape != (a2.shape[0], self.K) or not out.flags.c_contiguous:
+            raise PolarError("out must be a C-contiguous uint8 array of shape [B, K]")
+        if f32:
+            _check(lib().polar_decode_scl_llr_batch_f32(self._h, _p(a2, C.POINTER(C.c_float)), C.c_long(a2.shape[0]),
+                                                        C.c_int(list_size), _p(out, _u8p)))
+        else:
+            _check(lib().polar_decode_scl_llr_batch(self._h, _p(a2, _dp), C.c_long(a2.shape[0]), C.c_int(list_size),
+                                                    _p(out, _u8p)))
         return out[0] if single else out
 
     def decode_scl_llr_dev_f32(self, llr_ptr, B, list_size, out_ptr, pm_ptr=0, stream=None):

@@ -96,7 +96,7 @@ struct CopyPool {
     char *dst = nullptr; const char *src = nullptr; size_t bytes = 0;
     std::atomic<size_t> next{0};
     int pending = 0;
-    static constexpr size_t kSlice = (size_t)2 << 20;
+    static constexpr size_t kSlice = (size_t)1 << 20;
     void work() {
         for (;;) {
             const size_t off = next.fetch_add(kSlice);
@@ -122,7 +122,7 @@ struct CopyPool {
             });
     }
     void copy(void *d, const void *s, size_t n) {          // (the calling thread takes its share)
-        if (threads.empty() || n < 4 * kSlice) { memcpy(d, s, n); return; }
+        if (threads.empty() || n < 2 * kSlice) { memcpy(d, s, n); return; }
         {
             std::lock_guard<std::mutex> lk(m);
             dst = (char *)d; src = (const char *)s; bytes = n; next = 0; pending = (int)threads.size(); ++gen;
@@ -144,16 +144,19 @@ struct CopyPool {
 // The pipelined host-pointer decode path (host_decode): a ring of pinned staging slots and device slots, one copy stream,
 // two decode lanes (the handle itself and a private copy of its tables with its own scratch) on their own streams.
 struct HostPipe {
-    static constexpr int R = 4;
-    hipStream_t copy = nullptr, lane[2] = {nullptr, nullptr};
-    hipEvent_t h2d[R] = {}, done[R] = {};
-    void *pin_in[R] = {}; uint8_t *pin_out[R] = {};
-    void *d_in[R] = {}; uint8_t *d_out[R] = {};
+    static constexpr int kMaxLanes = 8, kMaxSlots = kMaxLanes + 2;
+    int R = 0;                               // ring slots in use (lanes + 2)
+    hipStream_t copy = nullptr, lane[kMaxLanes] = {};
+    hipEvent_t h2d[kMaxSlots] = {}, done[kMaxSlots] = {};
+    void *pin_in[kMaxSlots] = {}; uint8_t *pin_out[kMaxSlots] = {};
+    void *d_in[kMaxSlots] = {}; uint8_t *d_out[kMaxSlots] = {};
     size_t in_cap = 0, out_cap = 0;          // bytes per slot
-    polar_code *ctx1 = nullptr;              // the second lane's context (owned; dropped with the clones by every setter)
+    polar_code *ctx[kMaxLanes] = {};         // [0] unused (the handle itself); the others are owned, and dropped with the clones by every setter
     std::unique_ptr<CopyPool> pool;
-    // what the last pipelined call did (polar_debug_get "host_chunks", "host_chunk_cw", "host_lanes", "host_threads")
+    // what the last pipelined call did (polar_debug_get "host_chunks", "host_chunk_cw", "host_lanes", "host_threads",
+    // "host_us_copy_in" / "_wait" / "_copy_out" / "_total": where the calling thread spent its time)
     long last_chunks = 0, last_chunk_cw = 0, last_lanes = 0, last_threads = 0;
+    long us_copy_in = 0, us_wait = 0, us_copy_out = 0, us_total = 0;
 };
 
 struct polar_code {
@@ -209,12 +212,17 @@ struct polar_code {
         int fail_device = -1;        // (test hook) this worker reports a failure in its second round, before the collective
         int fail_collective = -1;    // (test hook) this worker's collective enqueue "fails" in its second round (after the barrier)
         long multi_timeout_s = 1800; // watchdog of a multi-device round: communicators are aborted when a round takes longer
+        long multi_grace_s = 10;     //   ... and how long each of its two further steps waits for the workers (MultiCtx::run_all)
+        bool force_workers = false;  // (test hook) worker threads (and so the watchdog) even with one device
+        int stall_device = -1;       // (test hook) this worker sleeps stall_ms in its second round before it launches anything
+        long stall_ms = 0;
         long lat_max_b = 0;          // batches up to this size take the one-codeword-per-wave kernels (0 = default, -1 = never)
         // the pipelined host-pointer path (host_decode): 0 = default everywhere
         long host_pipe_min_bytes = 0;  // input bytes from which a host-pointer batch is pipelined (-1 = never: one copy in, decode, one copy out)
         long host_chunk_bytes = 0;     // input bytes per chunk / staging slot
         long host_lanes = 0;           // decode lanes (1 or 2)
         long host_threads = 0;         // threads that copy between the caller's memory and the pinned slots (calling thread included)
+        long host_ramp = 0;            // -1: no small first chunks (all chunks equal)
     } knobs;
     // Monte-Carlo engine (device side): alive lists (double-buffered), their lengths, per-round counters
     DevBuf<uint64_t> d_alive[2];
@@ -225,6 +233,7 @@ struct polar_code {
     // streams + RCCL communicators of the last multi-device call, kept for the next one with the same device list
     // (an 8-rank ncclCommInitAll costs about as long as a short sweep runs)
     struct MultiCtx *multi = nullptr;
+    bool multi_poisoned = false;     // a multi-device round never returned (MultiCtx::run_all step 3): no further multi-device calls
     // zero-copy staging of the host-pointer entry points for the smallest batches (host_decode): pinned, device-mapped
     void *pin_in = nullptr, *pin_in_dev = nullptr;     // LLR rows
     uint8_t *pin_out = nullptr, *pin_out_dev = nullptr; // decoded bits [B][K] followed by one flag byte per codeword
@@ -233,6 +242,7 @@ struct polar_code {
     struct HostPipe *hpipe = nullptr;                   // pipelined staging of the large host-pointer batches (host_decode)
     // statistics of the last get_bler_quick* call (polar_debug_get)
     long last_rounds = 0, last_round_max_per_device = 0, worker_threads_started = 0;
+    std::vector<long> round_us;      //   wall time of every round of that call (polar_debug_get "round_us_min" / "_median" / "_max" / "_first")
     // tuning
     int waves_per_cu = 0, lds_log = 0, pipe = -1;
     bool prefix_on = true;
@@ -557,6 +567,9 @@ static void hostpipe_release(polar_code_t *h);      // (defined with host_decode
 
 void polar_destroy(polar_code_t *h) {
     if (!h) return;
+    // a multi-device round of this handle never returned (MultiCtx::run_all step 3): a worker thread may still be inside the
+    // driver with this handle's device contexts — nothing is freed
+    if (h->multi_poisoned) return;
     multi_release(h, false);
     for (polar_code *c : h->clones) polar_destroy(c);
     h->clones.clear();
@@ -609,7 +622,7 @@ int polar_get_crc_matrix(const polar_code_t *h, uint8_t *m) {
 static void drop_clones(polar_code_t *h) {
     for (polar_code *c : h->clones) polar_destroy(c);
     h->clones.clear();
-    if (h->hpipe && h->hpipe->ctx1) { polar_destroy(h->hpipe->ctx1); h->hpipe->ctx1 = nullptr; }   // (the second decode lane of host_decode)
+    if (h->hpipe) for (polar_code *&c : h->hpipe->ctx) if (c) { polar_destroy(c); c = nullptr; }   // (the extra decode lanes of host_decode)
 }
 
 // test hook: number of unfrozen leaves derive_tables() marked as weak (see there)
@@ -626,16 +639,22 @@ int polar_debug_set(polar_code_t *h, const char *key, long value) {
     else if (s == "no_tables") k.no_tables = value != 0;
     else if (s == "no_fuse_front") k.no_fuse_front = value != 0;
     else if (s == "no_prefix") h->prefix_on = (value == 0);          // (the all-frozen prefix decoded leaf by leaf by the list kernel itself)
-    else if (s == "no_rccl") k.no_rccl = value != 0;
-    else if (s == "force_rccl") k.force_rccl = value != 0;
-    else if (s == "share_device") k.share_device = value != 0;
+    // (the cached streams / communicators / worker threads of the last device list were built under the old setting)
+    else if (s == "no_rccl") { k.no_rccl = value != 0; multi_release(h, false); }
+    else if (s == "force_rccl") { k.force_rccl = value != 0; multi_release(h, false); }
+    else if (s == "share_device") { k.share_device = value != 0; multi_release(h, false); }
     else if (s == "fail_device") k.fail_device = (int)value;
     else if (s == "fail_collective") k.fail_collective = (int)value;
     else if (s == "lat_max_b") k.lat_max_b = value;
     else if (s == "host_pipe_min_bytes") k.host_pipe_min_bytes = value;
     else if (s == "host_chunk_bytes") k.host_chunk_bytes = value;
-    else if (s == "host_lanes") { if (value < 0 || value > 2) return fail(POLAR_E_ARG, "host_lanes must be 0 (default), 1 or 2"); k.host_lanes = value; }
+    else if (s == "host_lanes") { if (value < 0 || value > HostPipe::kMaxLanes) return fail(POLAR_E_ARG, "host_lanes must be 0 (default) or 1 .. %d", HostPipe::kMaxLanes); k.host_lanes = value; }
+    else if (s == "host_ramp") k.host_ramp = value;
     else if (s == "host_threads") { if (value < 0) return fail(POLAR_E_ARG, "host_threads must be >= 0"); k.host_threads = value; }
+    else if (s == "multi_grace_s") { if (value < 0) return fail(POLAR_E_ARG, "multi_grace_s must be >= 0"); k.multi_grace_s = value; }
+    else if (s == "force_workers") { k.force_workers = value != 0; multi_release(h, false); }
+    else if (s == "stall_device") k.stall_device = (int)value;
+    else if (s == "stall_ms") { if (value < 0) return fail(POLAR_E_ARG, "stall_ms must be >= 0"); k.stall_ms = value; }
     else if (s == "multi_timeout_s") { if (value < 0) return fail(POLAR_E_ARG, "multi_timeout_s must be >= 0 (0 = no watchdog)"); k.multi_timeout_s = value; }
     else return fail(POLAR_E_ARG, "polar_debug_set: unknown key '%s'", key);
     drop_clones(h);          // (the per-device contexts carry a copy of the knobs)
@@ -654,10 +673,25 @@ long polar_debug_get(const polar_code_t *h, const char *key) {
     if (s == "last_rounds") return h->last_rounds;
     if (s == "last_round_max_per_device") return h->last_round_max_per_device;
     if (s == "worker_threads_started") return h->worker_threads_started;
+    if (s.compare(0, 9, "round_us_") == 0) {
+        if (h->round_us.empty()) return 0;
+        std::vector<long> v(h->round_us);
+        if (s == "round_us_first") return v.front();
+        std::sort(v.begin(), v.end());
+        if (s == "round_us_min") return v.front();
+        if (s == "round_us_max") return v.back();
+        if (s == "round_us_median") return v[v.size() / 2];
+        return -1;
+    }
+    if (s == "multi_poisoned") return h->multi_poisoned ? 1 : 0;
     if (s == "host_chunks") return h->hpipe ? h->hpipe->last_chunks : 0;
     if (s == "host_chunk_cw") return h->hpipe ? h->hpipe->last_chunk_cw : 0;
     if (s == "host_lanes") return h->hpipe ? h->hpipe->last_lanes : 0;
     if (s == "host_threads") return h->hpipe ? h->hpipe->last_threads : 0;
+    if (s == "host_us_copy_in") return h->hpipe ? h->hpipe->us_copy_in : 0;
+    if (s == "host_us_wait") return h->hpipe ? h->hpipe->us_wait : 0;
+    if (s == "host_us_copy_out") return h->hpipe ? h->hpipe->us_copy_out : 0;
+    if (s == "host_us_total") return h->hpipe ? h->hpipe->us_total : 0;
     return -1;
 }
 
@@ -946,8 +980,8 @@ static void hostpipe_release(polar_code_t *h) {
     HostPipe *hp = h->hpipe;
     if (!hp) return;
     h->hpipe = nullptr;
-    if (hp->ctx1) polar_destroy(hp->ctx1);
-    for (int i = 0; i < HostPipe::R; ++i) {
+    for (polar_code *c : hp->ctx) if (c) polar_destroy(c);
+    for (int i = 0; i < HostPipe::kMaxSlots; ++i) {
         if (hp->pin_in[i]) (void)hipHostFree(hp->pin_in[i]);
         if (hp->pin_out[i]) (void)hipHostFree(hp->pin_out[i]);
         if (hp->d_in[i]) (void)hipFree(hp->d_in[i]);
@@ -963,44 +997,45 @@ static void hostpipe_release(polar_code_t *h) {
 static int hostpipe_ensure(polar_code_t *h, size_t in_slot, size_t out_slot, int lanes, int threads) {
     if (!h->hpipe) h->hpipe = new HostPipe;
     HostPipe *hp = h->hpipe;
-    if (!hp->copy) HIP_TRY(hipStreamCreateWithFlags(&hp->copy, hipStreamNonBlocking));
-    for (int l = 0; l < 2; ++l) if (!hp->lane[l]) HIP_TRY(hipStreamCreateWithFlags(&hp->lane[l], hipStreamNonBlocking));
-    for (int i = 0; i < HostPipe::R; ++i) {
+    const int R = lanes + 2;
+    // HIP multiplexes its streams onto a few hardware queues PER PRIORITY LEVEL (four by default), and two streams that share
+    // a queue take turns: a 64-MiB copy queued behind a 5-ms decode kernel, or the two decode lanes behind each other, and
+    // nothing overlaps (measured: rocprofv3 kernel trace of eight lanes — three queue ids, two kernels at a time). The three
+    // priority levels have queue pools of their own: the copy stream takes the high one, the first two lanes normal and low.
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (!hp->copy) HIP_TRY(hipStreamCreateWithPriority(&hp->copy, hipStreamNonBlocking, prio_greatest));
+    for (int l = 0; l < lanes; ++l)
+        if (!hp->lane[l]) HIP_TRY(hipStreamCreateWithPriority(&hp->lane[l], hipStreamNonBlocking, l == 1 ? prio_least : (prio_least + prio_greatest) / 2));
+    for (int i = 0; i < R; ++i) {
         if (!hp->h2d[i]) HIP_TRY(hipEventCreateWithFlags(&hp->h2d[i], hipEventDisableTiming));
         if (!hp->done[i]) HIP_TRY(hipEventCreateWithFlags(&hp->done[i], hipEventDisableTiming));
     }
-    if (hp->in_cap < in_slot) {
-        for (int i = 0; i < HostPipe::R; ++i) {
+    // (slots are sized together: a larger chunk replaces all of them, more lanes add slots of the current size)
+    if (hp->in_cap < in_slot || hp->out_cap < out_slot) {
+        for (int i = 0; i < HostPipe::kMaxSlots; ++i) {
             if (hp->pin_in[i]) (void)hipHostFree(hp->pin_in[i]);
             if (hp->d_in[i]) (void)hipFree(hp->d_in[i]);
-            hp->pin_in[i] = nullptr; hp->d_in[i] = nullptr;
-        }
-        hp->in_cap = 0;
-        for (int i = 0; i < HostPipe::R; ++i) {
-            HIP_TRY(hipHostMalloc(&hp->pin_in[i], in_slot, hipHostMallocDefault));
-            ++g_allocs;
-            HIP_TRY(hipMalloc(&hp->d_in[i], in_slot));
-        }
-        hp->in_cap = in_slot;
-    }
-    if (hp->out_cap < out_slot) {
-        for (int i = 0; i < HostPipe::R; ++i) {
             if (hp->pin_out[i]) (void)hipHostFree(hp->pin_out[i]);
             if (hp->d_out[i]) (void)hipFree(hp->d_out[i]);
-            hp->pin_out[i] = nullptr; hp->d_out[i] = nullptr;
+            hp->pin_in[i] = nullptr; hp->d_in[i] = nullptr; hp->pin_out[i] = nullptr; hp->d_out[i] = nullptr;
         }
-        hp->out_cap = 0;
-        for (int i = 0; i < HostPipe::R; ++i) {
-            HIP_TRY(hipHostMalloc((void **)&hp->pin_out[i], out_slot, hipHostMallocDefault));
-            ++g_allocs;
-            HIP_TRY(hipMalloc((void **)&hp->d_out[i], out_slot));
-        }
-        hp->out_cap = out_slot;
+        hp->in_cap = std::max(hp->in_cap, in_slot); hp->out_cap = std::max(hp->out_cap, out_slot);
     }
-    if (lanes > 1 && !hp->ctx1) {
-        hp->ctx1 = copy_ctx(h, h->device);
+    for (int i = 0; i < R; ++i) {
+        if (hp->pin_in[i]) continue;
+        ++g_allocs;
+        HIP_TRY(hipHostMalloc(&hp->pin_in[i], hp->in_cap, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&hp->d_in[i], hp->in_cap));
+        HIP_TRY(hipHostMalloc((void **)&hp->pin_out[i], hp->out_cap, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&hp->d_out[i], hp->out_cap));
+    }
+    hp->R = R;
+    for (int l = 1; l < lanes; ++l) {
+        if (hp->ctx[l]) continue;
+        hp->ctx[l] = copy_ctx(h, h->device);
         DevGuard g2;
-        int rc = ensure_device(hp->ctx1, g2);
+        int rc = ensure_device(hp->ctx[l], g2);
         g2.prev = -1;
         if (rc) return rc;
     }
@@ -1011,41 +1046,62 @@ static int hostpipe_ensure(polar_code_t *h, size_t in_slot, size_t out_slot, int
     return POLAR_OK;
 }
 
-static int host_decode_pipelined(polar_code_t *h, const void *llr, int llr_f32, long B, int L, uint8_t *out, long chunk_cw, int lanes, int threads) {
+static int host_decode_pipelined(polar_code_t *h, const void *llr, int llr_f32, long B, int L, uint8_t *out, long chunk_cw, int lanes, int threads, bool ramp) {
+    using clk = std::chrono::steady_clock;
+    auto us = [](clk::time_point a, clk::time_point b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+    const clk::time_point t_begin = clk::now();
     const size_t esz = llr_f32 ? sizeof(float) : sizeof(double);
     const size_t row_in = (size_t)h->N * esz, row_out = (size_t)h->K;
-    // equal chunks (a short last chunk would take another kernel family and its first-use allocations in mid-pipeline)
-    const long n_chunks = (B + chunk_cw - 1) / chunk_cw;
-    const long C = (((B + n_chunks - 1) / n_chunks) + 7) / 8 * 8;
+    // The chunks. A launch of the list kernels takes milliseconds whatever it carries (the N-step chain of one wave), so
+    // (a) the first chunks are SMALL — an eighth of the full size, doubling: the device starts a fraction of a millisecond
+    // after the call instead of after the first 128 MiB — and (b) the full-size chunks are equal (a short last one would be
+    // one more launch latency at the end of the call).
+    std::vector<long> start, size;
+    {
+        long done = 0;
+        if (ramp)
+            for (long c = std::max<long>(8, chunk_cw / 8 / 8 * 8); c < chunk_cw && B - done > 2 * c; c *= 2) { start.push_back(done); size.push_back(c); done += c; }
+        const long rest = B - done, n_full = (rest + chunk_cw - 1) / chunk_cw;
+        const long C = std::min(chunk_cw, (((rest + n_full - 1) / n_full) + 7) / 8 * 8);
+        for (; done < B; done += C) { start.push_back(done); size.push_back(std::min(C, B - done)); }
+    }
+    const long n_chunks = (long)start.size();
+    const long C = *std::max_element(size.begin(), size.end());
+    lanes = (int)std::min<long>(lanes, n_chunks);
     int rc = hostpipe_ensure(h, (size_t)C * row_in, (size_t)C * row_out, lanes, threads);
     if (rc) return rc;
     HostPipe *hp = h->hpipe;
     hp->last_chunks = n_chunks; hp->last_chunk_cw = C; hp->last_lanes = lanes; hp->last_threads = threads;
+    hp->us_copy_in = hp->us_wait = hp->us_copy_out = 0;
     // (the handle's scratch may still be in use by work the caller put on the null stream through this handle)
     HIP_TRY(hipStreamSynchronize(nullptr));
-    constexpr int R = HostPipe::R;
-    auto drain = [&] { (void)hipStreamSynchronize(hp->copy); for (hipStream_t s : hp->lane) (void)hipStreamSynchronize(s); };
+    const int R = hp->R;
+    auto drain = [&] { (void)hipStreamSynchronize(hp->copy); for (int l = 0; l < lanes; ++l) (void)hipStreamSynchronize(hp->lane[l]); };
     auto finish = [&](long j) -> int {                      // chunk j: wait for its bits, hand them to the caller
         const int slot = (int)(j % R);
-        const long b0 = j * C, nb = std::min(C, B - b0);
+        const clk::time_point t0 = clk::now();
         hipError_t e = hipEventSynchronize(hp->done[slot]);
+        const clk::time_point t1 = clk::now();
         if (e != hipSuccess) return fail(POLAR_E_DEVICE, "host pipeline: chunk %ld failed: %s", j, hipGetErrorString(e));
-        hp->pool->copy(out + (size_t)b0 * row_out, hp->pin_out[slot], (size_t)nb * row_out);
+        hp->pool->copy(out + (size_t)start[j] * row_out, hp->pin_out[slot], (size_t)size[j] * row_out);
+        hp->us_wait += us(t0, t1); hp->us_copy_out += us(t1, clk::now());
         return POLAR_OK;
     };
     long k = 0;
     for (; k < n_chunks && !rc; ++k) {
         const int slot = (int)(k % R);
-        const long b0 = k * C, nb = std::min(C, B - b0);
+        const long b0 = start[k], nb = size[k];
         if (k >= R && (rc = finish(k - R))) break;          // (frees the slot: its H2D, decode and D2H are all behind `done`)
+        const clk::time_point t0 = clk::now();
         hp->pool->copy(hp->pin_in[slot], (const char *)llr + (size_t)b0 * row_in, (size_t)nb * row_in);
+        hp->us_copy_in += us(t0, clk::now());
         hipError_t e = hipMemcpyAsync(hp->d_in[slot], hp->pin_in[slot], (size_t)nb * row_in, hipMemcpyHostToDevice, hp->copy);
         if (e == hipSuccess) e = hipEventRecord(hp->h2d[slot], hp->copy);
         const int l = (int)(k % lanes);
         hipStream_t st = hp->lane[l];
         if (e == hipSuccess) e = hipStreamWaitEvent(st, hp->h2d[slot], 0);
         if (e != hipSuccess) { rc = fail(POLAR_E_DEVICE, "host pipeline: copy of chunk %ld: %s", k, hipGetErrorString(e)); break; }
-        if ((rc = decode_impl(l ? hp->ctx1 : h, hp->d_in[slot], llr_f32, nb, nullptr, L, hp->d_out[slot], nullptr, st, nullptr, nullptr))) break;
+        if ((rc = decode_impl(l ? hp->ctx[l] : h, hp->d_in[slot], llr_f32, nb, nullptr, L, hp->d_out[slot], nullptr, st, nullptr, nullptr))) break;
         e = hipMemcpyAsync(hp->pin_out[slot], hp->d_out[slot], (size_t)nb * row_out, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipEventRecord(hp->done[slot], st);
         if (e != hipSuccess) { rc = fail(POLAR_E_DEVICE, "host pipeline: result copy of chunk %ld: %s", k, hipGetErrorString(e)); break; }
@@ -1053,6 +1109,7 @@ static int host_decode_pipelined(polar_code_t *h, const void *llr, int llr_f32, 
     if (rc) { const std::string msg = g_err; drain(); g_err = msg; return rc; }
     for (long j = std::max<long>(0, n_chunks - R); j < n_chunks; ++j)
         if ((rc = finish(j))) { const std::string msg = g_err; drain(); g_err = msg; return rc; }
+    hp->us_total = us(t_begin, clk::now());
     return POLAR_OK;
 }
 
@@ -1072,14 +1129,26 @@ static int host_decode(polar_code_t *h, const void *llr, int llr_f32, long B, in
         const polar_code::Knobs &kn = h->knobs;
         const size_t min_bytes = kn.host_pipe_min_bytes > 0 ? (size_t)kn.host_pipe_min_bytes : (size_t)32 << 20;
         if (kn.host_pipe_min_bytes >= 0 && in_bytes >= min_bytes) {
-            // chunks of 64 MiB of LLRs (4096 codewords of N = 2048 in doubles: half of what the list-of-32 kernel holds at a
-            // time, so that two lanes keep the device full), at least four chunks per batch
-            size_t cb = kn.host_chunk_bytes > 0 ? (size_t)kn.host_chunk_bytes : (size_t)64 << 20;
+            // full-size chunks: 64 MiB of LLRs at list size 1 (the link is the bound, its kernel answers in a millisecond). The
+            // list kernels' launches take 4 .. 8 ms whatever they carry, and the chunks in flight must cover what the link
+            // delivers meanwhile: 8192 codewords of N = 2048 for the lists of 17 and more (what the device holds at a time:
+            // 128 MiB of doubles), 128 MiB of doubles or floats in between (three lanes x 16384 float rows); at least four
+            // full-size chunks per batch
+            const long fill_cw = 8192L * 2048 / h->N;
+            const bool fills = L > 1 && (long)h->num_cu * 16 * (64 / pow2ceil(L)) <= fill_cw;
+            size_t cb = kn.host_chunk_bytes > 0 ? (size_t)kn.host_chunk_bytes : (L == 1 ? (size_t)64 << 20 : fills ? (size_t)fill_cw * h->N * esz : (size_t)128 << 20);
             if (kn.host_chunk_bytes <= 0) cb = std::min(cb, std::max<size_t>(in_bytes / 4, (size_t)8 << 20));
             const long chunk_cw = std::max<long>(8, (long)(cb / ((size_t)h->N * esz)) / 8 * 8);
-            const int lanes = kn.host_lanes == 1 ? 1 : 2;
+            // decode lanes: HIP multiplexes its streams onto four hardware queues, two streams on one queue take turns — two
+            // lanes for list size 1 and for the lists whose full-size chunk fills the device, three in between
+            int lanes = (int)kn.host_lanes;
+            if (lanes <= 0) lanes = (L == 1 || (long)h->num_cu * 16 * (64 / pow2ceil(L)) <= chunk_cw) ? 2 : 3;
+            // small first chunks (host_decode_pipelined) unless one full-size chunk already fills the device: the list-of-32
+            // kernel runs such a chunk as ONE round of resident waves, and three more launches cost it more than the early start
+            // returns (headline, 65536 codewords: 0.87 of the device-resident rate with them, 0.90 .. 0.93 without)
+            const bool ramp = kn.host_ramp > 0 || (kn.host_ramp == 0 && (L == 1 || (long)h->num_cu * 16 * (64 / pow2ceil(L)) > chunk_cw));
             const int threads = kn.host_threads > 0 ? (int)std::min<long>(kn.host_threads, 64) : std::max(1, std::min(8, usable_cpus() / 2));
-            if (B > chunk_cw) return host_decode_pipelined(h, llr, llr_f32, B, L, out, chunk_cw, lanes, threads);
+            if (B > chunk_cw) return host_decode_pipelined(h, llr, llr_f32, B, L, out, chunk_cw, lanes, threads, ramp);
         }
     }
     if (L == 1 && mode != 1 && use_sc_lat(h, B) && B <= 64) {
@@ -1521,15 +1590,23 @@ Rccl g_rccl;
 constexpr int kNcclUint64 = 5, kNcclSum = 0;     // rccl.h: ncclUint64, ncclSum
 std::atomic<int> g_comm_inits{0};                // test hook (polar_debug_comm_inits): ncclCommInitAll calls so far
 
-// all worker threads of a round meet here before the collective: either every one of them enters ncclAllReduce or none does
+// all worker threads of a round meet here before the collective: either every one of them enters ncclAllReduce or none does.
+// Abortable: the watchdog of a round that takes too long releases everybody who waits here (wait() then returns false, now
+// and for the rest of the context's life — a context whose round timed out is torn down, never reused).
 struct HostBarrier {
-    std::mutex m; std::condition_variable cv; int n, waiting = 0; unsigned gen = 0;
+    std::mutex m; std::condition_variable cv; int n, waiting = 0; unsigned gen = 0; bool aborted = false;
     explicit HostBarrier(int n_) : n(n_) {}
-    void wait() {
+    bool wait() {
         std::unique_lock<std::mutex> lk(m);
+        if (aborted) return false;
         const unsigned g = gen;
-        if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); }
-        else cv.wait(lk, [&] { return gen != g; });
+        if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); return true; }
+        cv.wait(lk, [&] { return gen != g || aborted; });
+        return gen != g;
+    }
+    void abort() {
+        { std::lock_guard<std::mutex> lk(m); aborted = true; }
+        cv.notify_all();
     }
 };
 
@@ -1539,24 +1616,42 @@ struct HostBarrier {
 struct MultiCtx {
     std::vector<int> devs;               // as listed by the caller
     std::vector<hipStream_t> streams;
-    std::vector<void *> comms;           // empty without RCCL
     bool rccl = false;
+    // The communicators (empty without RCCL). Workers read them, a worker that learns of a failed round aborts its own,
+    // and the watchdog aborts what is left when a worker does not answer: every access goes through get_comm / take_comm
+    // (a mutex; take_comm hands a communicator to exactly ONE caller, so none is aborted or destroyed twice).
+    std::vector<void *> comms;
+    std::mutex cm;
+    void *get_comm(int d) { std::lock_guard<std::mutex> lk(cm); return d < (int)comms.size() ? comms[d] : nullptr; }
+    void *take_comm(int d) {
+        std::lock_guard<std::mutex> lk(cm);
+        if (d >= (int)comms.size()) return nullptr;
+        void *c = comms[d]; comms[d] = nullptr; return c;
+    }
     // Persistent worker pool: one thread per device, created with the context and parked between rounds (round 3 created
-    // and joined n_dev threads every round). run_all() hands every worker the same job and waits for all of them; with a
-    // watchdog: when a round takes longer than `timeout_s` the communicators are aborted from the waiting thread, which
-    // releases workers blocked in a collective that a peer never entered or never finished.
+    // and joined n_dev threads every round). run_all() hands every worker the same job and waits for all of them, with a
+    // watchdog in three bounded steps when a round takes longer than `timeout_s`:
+    //   1. SIGNAL: `abort_req` is raised and the host barrier aborted. Workers wait for their streams by polling
+    //      (wait_stream), see the flag and abort their OWN communicator — which releases a stream stuck behind a collective
+    //      a peer never entered or never finished; workers waiting in the barrier are released by its abort.
+    //   2. after `grace_s`: a worker blocked INSIDE an RCCL call cannot poll; the communicators nobody took yet are aborted
+    //      from the waiting thread (ncclCommAbort exists for that).
+    //   3. after another `grace_s`: give up. `stuck` is set, the caller returns an error WITHOUT joining: the context, its
+    //      threads and the handle's device contexts are leaked on purpose (a thread that never comes back from the driver
+    //      cannot be cancelled), the handle refuses further multi-device calls.
     std::vector<std::thread> threads;
     std::mutex m;
     std::condition_variable cv_job, cv_done;
     std::function<void(int)> job;
     unsigned gen = 0;
     int pending = 0;
-    bool quit = false, timed_out = false;
+    bool quit = false, timed_out = false, stuck = false;
+    std::atomic<bool> abort_req{false};
     std::unique_ptr<HostBarrier> bar;
 
-    void start_workers(int n) {
+    void start_workers(int n, bool force_threads) {
         bar.reset(new HostBarrier(n));
-        if (n <= 1) return;                          // a single device runs on the calling thread
+        if (n <= 1 && !force_threads) return;        // a single device runs on the calling thread (no watchdog then)
         for (int d = 0; d < n; ++d)
             threads.emplace_back([this, d] {
                 unsigned seen = 0;
@@ -1577,25 +1672,42 @@ struct MultiCtx {
                 }
             });
     }
-    void abort_comms() {                             // (any thread; ncclCommAbort exists to be called on a stuck communicator)
-        for (size_t d = 0; d < comms.size(); ++d)
-            if (comms[d] && g_rccl.CommAbort) { (void)g_rccl.CommAbort(comms[d]); comms[d] = nullptr; }
+    void abort_own(int d) {                          // (worker d, or the watchdog for whoever did not answer)
+        void *c = take_comm(d);
+        if (c && g_rccl.CommAbort) (void)g_rccl.CommAbort(c);
     }
-    void run_all(const std::function<void(int)> &f, long timeout_s) {
+    // Wait for a worker's stream without giving up the ability to react: hipStreamSynchronize cannot be interrupted, a
+    // polling loop can — when the watchdog raises abort_req the worker aborts its own communicator and keeps waiting (the
+    // aborted collective completes with an error, the stream drains).
+    hipError_t wait_stream(int d) {
+        if (threads.empty()) return hipStreamSynchronize(streams[d]);
+        bool aborted_own = false;
+        for (unsigned spins = 0;; ++spins) {
+            const hipError_t q = hipStreamQuery(streams[d]);
+            if (q != hipErrorNotReady) return q;
+            if (abort_req.load(std::memory_order_relaxed) && !aborted_own) { abort_own(d); aborted_own = true; }
+            if (spins < 2000) std::this_thread::yield();
+            else std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+    }
+    void run_all(const std::function<void(int)> &f, long timeout_s, long grace_s) {
         const int n = (int)devs.size();
         if (threads.empty()) { for (int d = 0; d < n; ++d) f(d); return; }
         std::unique_lock<std::mutex> lk(m);
         job = f; pending = n; ++gen;
         cv_job.notify_all();
-        if (timeout_s > 0) {
-            if (!cv_done.wait_for(lk, std::chrono::seconds(timeout_s), [&] { return pending == 0; })) {
-                timed_out = true;
-                lk.unlock();
-                abort_comms();                       // frees workers blocked in hipStreamSynchronize behind a dead collective
-                lk.lock();
-                cv_done.wait(lk, [&] { return pending == 0; });
-            }
-        } else cv_done.wait(lk, [&] { return pending == 0; });
+        auto done = [&] { return pending == 0; };
+        if (timeout_s <= 0) { cv_done.wait(lk, done); return; }
+        if (cv_done.wait_for(lk, std::chrono::seconds(timeout_s), done)) return;
+        timed_out = true;
+        abort_req.store(true);
+        bar->abort();                                // step 1: signal
+        if (cv_done.wait_for(lk, std::chrono::seconds(grace_s), done)) return;
+        lk.unlock();
+        for (int d = 0; d < n; ++d) abort_own(d);    // step 2: whatever no worker took
+        lk.lock();
+        if (cv_done.wait_for(lk, std::chrono::seconds(grace_s), done)) return;
+        stuck = true;                                // step 3: bounded in every case
     }
     void stop_workers() {
         {
@@ -1614,14 +1726,20 @@ void multi_release(polar_code *h, bool abort_comms) {
     MultiCtx *m = h->multi;
     if (!m) return;
     h->multi = nullptr;
+    if (m->stuck) {
+        // a worker never came back from the driver: nothing it may still touch is freed (MultiCtx::run_all step 3)
+        for (auto &t : m->threads) t.detach();
+        h->multi_poisoned = true;
+        return;
+    }
     m->stop_workers();
     int prev = -1;
     (void)hipGetDevice(&prev);
     for (size_t d = 0; d < m->comms.size(); ++d)
-        if (m->comms[d]) {
+        if (void *c = m->take_comm((int)d)) {
             // after a failed round a rank may be stuck inside a collective: abort, do not wait for it
-            if (abort_comms && g_rccl.CommAbort) (void)g_rccl.CommAbort(m->comms[d]);
-            else (void)g_rccl.CommDestroy(m->comms[d]);
+            if (abort_comms && g_rccl.CommAbort) (void)g_rccl.CommAbort(c);
+            else (void)g_rccl.CommDestroy(c);
         }
     for (size_t d = 0; d < m->streams.size(); ++d)
         if (m->streams[d]) { (void)hipSetDevice(m->devs[d]); (void)hipStreamDestroy(m->streams[d]); }
@@ -1702,6 +1820,7 @@ int bler_impl(polar_code_t *h, int constellation, const int *devices, int n_dev,
                 dup = true;
             }
     }
+    if (h->multi_poisoned) return fail(POLAR_E_DEVICE, "an earlier multi-device round of this handle never returned: the handle accepts no further multi-device calls");
     const bool want_rccl = (n_dev > 1 || h->knobs.force_rccl) && !h->knobs.no_rccl && !dup;
     if (h->multi && (h->multi->devs != devs || (want_rccl && !h->multi->rccl && g_rccl.load()))) multi_release(h, false);
     for (int d = 0; d < n_dev; ++d) {
@@ -1740,85 +1859,125 @@ int bler_impl(polar_code_t *h, int constellation, const int *devices, int n_dev,
             m->rccl = (g_rccl.CommInitAll(m->comms.data(), n_dev, devs.data()) == 0);
             if (!m->rccl) m->comms.clear();
         }
-        m->start_workers(n_dev);
+        m->start_workers(n_dev, h->knobs.force_workers);
         h->worker_threads_started += (long)m->threads.size();
     }
     MultiCtx *mc = h->multi;
-    const std::vector<hipStream_t> &streams = mc->streams;
     const bool rccl = mc->rccl && want_rccl;
     if (used_rccl) *used_rccl = rccl ? 1 : 0;
     int rc_all = POLAR_OK;
     std::string err_msg;
-    const int fail_dev = h->knobs.fail_device, fail_coll = h->knobs.fail_collective;     // (test hooks)
-    int round_no = 0;
     h->last_rounds = 0; h->last_round_max_per_device = 0;
-    std::vector<int> rcs(n_dev);
-    std::vector<std::string> msgs(n_dev);
-    std::vector<long> Td(n_dev);
-    std::vector<std::vector<unsigned long long>> host_ctr(n_dev, std::vector<unsigned long long>((size_t)2 * P, 0));
-    for (long done = 0; done < max_runs; ++round_no) {
+    h->round_us.clear();
+    // Everything a worker touches during a round lives in ONE shared object that the job holds by value: a worker the
+    // watchdog had to give up on (MultiCtx::run_all step 3) may wake up after this function has returned.
+    struct Job {
+        int n_dev, P, n_e, n_L, constellation, fail_dev, fail_coll, stall_dev;
+        long stall_ms;
+        uint64_t seed;
+        bool rccl;
+        MultiCtx *mc;
+        std::vector<polar_code *> ctx;
+        std::vector<double> axis;
+        std::vector<uint8_t> Ls, en;
+        std::vector<int> rcs;
+        std::vector<std::string> msgs;
+        std::vector<long> Td;
+        std::vector<std::vector<unsigned long long>> host_ctr;
+        long T = 0, done = 0;
+        int round_no = 0;
+        std::atomic<int> n_failed{0}, n_failed_coll{0};
+    };
+    auto job = std::make_shared<Job>();
+    job->n_dev = n_dev; job->P = P; job->n_e = n_e; job->n_L = n_L; job->constellation = constellation;
+    job->fail_dev = h->knobs.fail_device; job->fail_coll = h->knobs.fail_collective;       // (test hooks)
+    job->stall_dev = h->knobs.stall_device; job->stall_ms = h->knobs.stall_ms;
+    job->seed = seed; job->rccl = rccl; job->mc = mc; job->ctx = ctx;
+    job->axis.assign(ebno, ebno + n_e); job->Ls.assign(Ls, Ls + n_L); job->en.assign(P, 1);
+    job->rcs.assign(n_dev, POLAR_OK); job->msgs.assign(n_dev, std::string()); job->Td.assign(n_dev, 0);
+    job->host_ctr.assign(n_dev, std::vector<unsigned long long>((size_t)2 * P, 0));
+    auto worker = [job](int d) {
+        Job &J = *job;
+        MultiCtx *mc = J.mc;
+        polar_code *c = J.ctx[d];
+        const int n_dev = J.n_dev, P = J.P;
+        hipStream_t st = mc->streams[d];
+        J.Td[d] = (J.T - d + n_dev - 1) / n_dev;
+        int rc = POLAR_OK;
+        std::string msg;
+        if (hipSetDevice(c->device) != hipSuccess) { rc = POLAR_E_DEVICE; msg = "hipSetDevice failed"; }
+        else if (d == J.fail_dev && J.round_no == 1) { rc = POLAR_E_DEVICE; msg = "injected failure (fail_device)"; }
+        else {
+            // (test hook: this worker does not answer for stall_ms in its second round — a hang outside every collective)
+            if (d == J.stall_dev && J.round_no == 1) std::this_thread::sleep_for(std::chrono::milliseconds(J.stall_ms));
+            if (J.Td[d] > 0)
+                rc = mc_round_launch(c, J.constellation, J.seed, (uint64_t)(J.done + d), J.Td[d], n_dev, J.axis.data(), J.n_e, J.Ls.data(), J.n_L, J.en.data(), st);
+            else
+                rc = (c->d_mc_ctr.ensure((size_t)2 * P) || hipMemsetAsync(c->d_mc_ctr.p, 0, (size_t)2 * P * 8, st) != hipSuccess) ? POLAR_E_DEVICE : POLAR_OK;
+            if (rc) msg = polar_last_error();
+        }
+        // (1) every worker learns whether ALL of them got this far: either every one enters the collective or none does
+        // (a lone rank skipping it would leave the others blocked in it for good)
+        if (rc) ++J.n_failed;
+        const bool met = n_dev > 1 ? mc->bar->wait() : true;        // false: the watchdog aborted the barrier
+        const bool round_ok = met && J.n_failed.load() == 0 && !mc->abort_req.load();
+        if (round_ok) {
+            // sum of the round's counters over the devices (xGMI), in place on every device
+            bool coll_failed = false;
+            if (d == J.fail_coll && J.round_no == 1) coll_failed = true;       // (test hook: the enqueue "fails" on this rank only)
+            else if (J.rccl) {
+                void *comm = mc->get_comm(d);
+                if (!comm || g_rccl.AllReduce(c->d_mc_ctr.p, c->d_mc_ctr.p, (size_t)2 * P, kNcclUint64, kNcclSum, comm, st) != 0) coll_failed = true;
+            }
+            if (coll_failed) { rc = POLAR_E_DEVICE; msg = (d == J.fail_coll && J.round_no == 1) ? "injected failure (fail_collective)" : "ncclAllReduce failed"; ++J.n_failed_coll; }
+            // (2) a rank whose enqueue failed AFTER the first barrier would leave its peers blocked behind a collective that
+            // never completes: everybody meets again, and when any enqueue failed (or the watchdog fired) every rank aborts
+            // its OWN communicator BEFORE it waits for its stream
+            const bool met2 = n_dev > 1 ? mc->bar->wait() : true;
+            if (!met2 || J.n_failed_coll.load() != 0) {
+                if (J.rccl) mc->abort_own(d);
+                if (!rc) { rc = POLAR_E_DEVICE; msg = met2 ? "round aborted: the counter reduction failed on another device" : "round aborted: watchdog"; }
+            } else if (!J.rccl || d == 0) {
+                if (hipMemcpyAsync(J.host_ctr[d].data(), c->d_mc_ctr.p, (size_t)2 * P * 8, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = POLAR_E_DEVICE; msg = "counter copy failed"; }
+            }
+        } else if (!rc) { rc = POLAR_E_DEVICE; msg = (met && !mc->abort_req.load()) ? "round aborted: another device failed" : "round aborted: watchdog"; }
+        if (mc->wait_stream(d) != hipSuccess && !rc) { rc = POLAR_E_DEVICE; msg = "stream synchronize failed"; }
+        J.rcs[d] = rc; J.msgs[d] = msg;
+    };
+    for (long done = 0; done < max_runs;) {
         bool any = false;
         for (int i = 0; i < P; ++i) { en[i] = (err[i] <= (uint64_t)max_err); any |= en[i]; }   // :725
         if (!any) break;
         const long T = next_round(batch, max_err, done, max_runs, n_dev);      // trials of this round, all devices together
         // device d simulates the trials done + d, done + d + n_dev, ... (counter-based inputs: the union does not
         // depend on n_dev)
-        std::fill(rcs.begin(), rcs.end(), POLAR_OK);
-        for (auto &s_ : msgs) s_.clear();
-        std::atomic<int> n_failed{0}, n_failed_coll{0};
-        HostBarrier &bar = *mc->bar;
-        auto worker = [&](int d) {
-            polar_code *c = ctx[d];
-            Td[d] = (T - d + n_dev - 1) / n_dev;
-            int rc = POLAR_OK;
-            if (hipSetDevice(c->device) != hipSuccess) { rc = POLAR_E_DEVICE; msgs[d] = "hipSetDevice failed"; }
-            else if (d == fail_dev && round_no == 1) { rc = POLAR_E_DEVICE; msgs[d] = "injected failure (fail_device)"; }
-            else if (Td[d] > 0)
-                rc = mc_round_launch(c, constellation, seed, (uint64_t)(done + d), Td[d], n_dev, ebno, n_e, Ls, n_L, en.data(), streams[d]);
-            else
-                rc = (c->d_mc_ctr.ensure((size_t)2 * P) || hipMemsetAsync(c->d_mc_ctr.p, 0, (size_t)2 * P * 8, streams[d]) != hipSuccess) ? POLAR_E_DEVICE : POLAR_OK;
-            if (rc && msgs[d].empty()) msgs[d] = polar_last_error();
-            // (1) every worker learns whether ALL of them got this far: either every one enters the collective or none does
-            // (a lone rank skipping it would leave the others blocked in it for good)
-            if (rc) ++n_failed;
-            if (n_dev > 1) bar.wait();
-            const bool round_ok = (n_failed.load() == 0);
-            bool coll_failed = false;
-            if (round_ok) {
-                // sum of the round's counters over the devices (xGMI), in place on every device
-                if (d == fail_coll && round_no == 1) coll_failed = true;       // (test hook: the enqueue "fails" on this rank only)
-                else if (rccl && g_rccl.AllReduce(c->d_mc_ctr.p, c->d_mc_ctr.p, (size_t)2 * P, kNcclUint64, kNcclSum, mc->comms[d], streams[d]) != 0)
-                    coll_failed = true;
-                if (coll_failed) { rc = POLAR_E_DEVICE; msgs[d] = (d == fail_coll && round_no == 1) ? "injected failure (fail_collective)" : "ncclAllReduce failed"; ++n_failed_coll; }
-                // (2) a rank whose enqueue failed AFTER the first barrier would leave its peers blocked in
-                // hipStreamSynchronize behind a collective that never completes: everybody meets again, and when any
-                // enqueue failed every rank aborts its own communicator BEFORE it synchronises
-                if (n_dev > 1) bar.wait();
-                if (n_failed_coll.load() != 0) {
-                    if (rccl && mc->comms[d] && g_rccl.CommAbort) { (void)g_rccl.CommAbort(mc->comms[d]); mc->comms[d] = nullptr; }
-                    if (!rc) { rc = POLAR_E_DEVICE; msgs[d] = "round aborted: the counter reduction failed on another device"; }
-                } else if (!rccl || d == 0) {
-                    if (hipMemcpyAsync(host_ctr[d].data(), c->d_mc_ctr.p, (size_t)2 * P * 8, hipMemcpyDeviceToHost, streams[d]) != hipSuccess) { rc = POLAR_E_DEVICE; msgs[d] = "counter copy failed"; }
-                }
-            } else if (!rc) { rc = POLAR_E_DEVICE; msgs[d] = "round aborted: another device failed"; }
-            if (hipStreamSynchronize(streams[d]) != hipSuccess && !rc) { rc = POLAR_E_DEVICE; msgs[d] = "stream synchronize failed"; }
-            rcs[d] = rc;
-        };
-        mc->run_all(worker, h->knobs.multi_timeout_s);
-        if (mc->timed_out) { rc_all = POLAR_E_DEVICE; err_msg = "a multi-device round exceeded the watchdog (" + std::to_string(h->knobs.multi_timeout_s) + " s): communicators aborted"; }
+        job->en = en; job->T = T; job->done = done;
+        std::fill(job->rcs.begin(), job->rcs.end(), POLAR_OK);
+        for (auto &s_ : job->msgs) s_.clear();
+        job->n_failed = 0; job->n_failed_coll = 0;
+        const auto t_round = std::chrono::steady_clock::now();
+        mc->run_all(worker, h->knobs.multi_timeout_s, h->knobs.multi_grace_s);
+        h->round_us.push_back((long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_round).count());
+        if (mc->timed_out) {
+            rc_all = POLAR_E_DEVICE;
+            err_msg = "a multi-device round exceeded the watchdog (" + std::to_string(h->knobs.multi_timeout_s) + " s): communicators aborted" +
+                      (mc->stuck ? "; a worker never returned, the handle accepts no further multi-device calls" : "");
+        }
+        if (mc->stuck) break;                        // (the job's vectors may still be written by the worker that is stuck)
         // report the device that failed first-hand, not a peer that was merely told to stop
         for (int pass = 0; pass < 2 && !rc_all; ++pass)
             for (int d = 0; d < n_dev; ++d)
-                if (rcs[d] && (pass == 1 || msgs[d].compare(0, 13, "round aborted") != 0)) { rc_all = rcs[d]; err_msg = "device " + std::to_string(devs[d]) + ": " + msgs[d]; break; }
+                if (job->rcs[d] && (pass == 1 || job->msgs[d].compare(0, 13, "round aborted") != 0)) { rc_all = job->rcs[d]; err_msg = "device " + std::to_string(devs[d]) + ": " + job->msgs[d]; break; }
         if (rc_all) break;
         for (int i = 0; i < P; ++i) {
             if (!en[i]) continue;
-            for (int d = 0; d < (rccl ? 1 : n_dev); ++d) { err[i] += host_ctr[d][2 * i]; bit[i] += host_ctr[d][2 * i + 1]; }
+            for (int d = 0; d < (rccl ? 1 : n_dev); ++d) { err[i] += job->host_ctr[d][2 * i]; bit[i] += job->host_ctr[d][2 * i + 1]; }
             run[i] += (uint64_t)T;
         }
         done += T;
+        ++job->round_no;
         ++h->last_rounds;
-        h->last_round_max_per_device = std::max(h->last_round_max_per_device, Td[0]);
+        h->last_round_max_per_device = std::max(h->last_round_max_per_device, job->Td[0]);
     }
     // a failed round leaves the communicators in an unknown state: abort and rebuild them next time
     if (rc_all) multi_release(h, true);

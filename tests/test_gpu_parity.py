@@ -89,24 +89,36 @@ def test_ragged_batches_and_empty(built_lib, oracle_built):
 
 @pytest.mark.parametrize("L", [1, 2, 4, 32])
 def test_pipelined_host_batches_at_chunk_boundaries(built_lib, oracle_built, L):
-    """Large host-pointer batches are cut into chunks (pinned staging, copy stream, two decode lanes: polar_host.cpp
+    """Large host-pointer batches are cut into chunks (pinned staging, copy stream, several decode lanes: polar_host.cpp
     host_decode_pipelined). Forced here on small batches with tiny chunks: a batch that is one codeword short of / exactly /
-    one codeword over a whole number of chunks, fewer chunks than ring slots and many more, one lane and two, doubles and
+    one codeword over a whole number of chunks, fewer chunks than ring slots and many more, one / two / five lanes, doubles and
     floats — every row must be what the unpipelined path returns (== the oracle), in its place."""
     o, g = _pair(8, 128, 4)
     llr, _ = o.synth_llr(11, 0, 1000, o.snr_sqrt_linear(1.5))
     want = o.decode_scl_llr(llr, L)
     row = 256 * 8
     g.debug_set("host_pipe_min_bytes", 1)
-    for lanes in (1, 2):
+    g.debug_set("host_ramp", -1)                 # equal chunks: their number is then ceil(B / chunk)
+    for lanes in (1, 2, 5):
         g.debug_set("host_lanes", lanes)
         for chunk_cw, Bs in ((8, (9, 15, 16, 17, 31, 33, 100)), (64, (65, 127, 128, 129, 448, 1000)), (200, (201, 799, 1000))):
             g.debug_set("host_chunk_bytes", chunk_cw * row)
             for B in Bs:
                 got = g.decode_scl_llr(llr[:B], L)
                 assert g.debug_get("host_chunks") == -(-B // chunk_cw), (B, chunk_cw, g.debug_get("host_chunks"))
-                assert g.debug_get("host_lanes") == lanes
+                assert g.debug_get("host_lanes") == min(lanes, -(-B // chunk_cw))
                 assert (got == want[:B]).all(), (L, lanes, chunk_cw, B)
+    # the default schedule: small first chunks (an eighth of the full size, doubling), then equal full-size ones
+    g.debug_set("host_ramp", 0)
+    g.debug_set("host_lanes", 3)
+    for chunk_cw, Bs in ((64, (65, 100, 129, 500, 1000)), (512, (513, 1000))):
+        g.debug_set("host_chunk_bytes", chunk_cw * row)
+        for B in Bs:
+            got = g.decode_scl_llr(llr[:B], L)
+            assert g.debug_get("host_chunks") >= 2 and g.debug_get("host_chunk_cw") <= chunk_cw
+            assert (got == want[:B]).all(), (L, "ramp", chunk_cw, B)
+    g.debug_set("host_ramp", -1)
+    g.debug_set("host_lanes", 2)
     # floats: half the bytes per row, the chunk is then twice the codewords
     g.debug_set("host_chunk_bytes", 64 * row)
     l32 = llr.astype(np.float32)
@@ -129,10 +141,11 @@ def test_pipelined_host_batches_at_chunk_boundaries(built_lib, oracle_built, L):
 
 
 def test_pipelined_host_batch_at_the_default_settings(built_lib):
-    """The defaults (no knob): 16 384 codewords of the headline code at list size 1 (256 MiB of doubles: four chunks of 64 MiB)
+    """The defaults (no knob): 16 384 codewords of the headline code at list sizes 1 and 4 (256 MiB of doubles)
     through the host-pointer entry point == the device-resident decode of the same rows; a CRC matrix set in between
-    reaches both decode lanes."""
+    reaches every decode lane."""
     import ctypes as C
+    import polar_amd
     import torch
     C.CDLL(None).srand(C.c_uint(1))
     g = polar_amd.PolarCode(11, 1024, 0.32, 16)
@@ -145,7 +158,8 @@ def test_pipelined_host_batch_at_the_default_settings(built_lib):
         g.decode_scl_llr_dev(d_llr.data_ptr(), B, L, d_out.data_ptr())
         torch.cuda.synchronize()
         got = g.decode_scl_llr(llr, L)
-        assert g.debug_get("host_chunks") == 4 and g.debug_get("host_lanes") == 2
+        # (256 MiB: full-size chunks of 64 MiB, i.e. 4096 codewords; 512 + 1024 + 2048 first, then 4 x 3200)
+        assert g.debug_get("host_chunks") == 7 and g.debug_get("host_lanes") == (2 if L == 1 else 3)
         assert (got == d_out.cpu().numpy()).all()
     m = g.crc_matrix
     g.crc_matrix = m[::-1].copy()

@@ -20,11 +20,12 @@ import torch
 import bench
 
 SWEEP = [("off (one copy in, decode, one copy out)", {"host_pipe_min_bytes": -1}),
-         ("one lane", {"host_lanes": 1}),
-         ("chunk 16 MiB", {"host_chunk_bytes": 16 << 20}), ("chunk 32 MiB", {"host_chunk_bytes": 32 << 20}),
-         ("chunk 128 MiB", {"host_chunk_bytes": 128 << 20}),
-         ("1 thread", {"host_threads": 1}), ("2 threads", {"host_threads": 2}), ("4 threads", {"host_threads": 4}),
-         ("12 threads", {"host_threads": 12}), ("16 threads", {"host_threads": 16})]
+         ("no ramp", {"host_ramp": -1}),
+         ("one lane", {"host_lanes": 1}), ("two lanes", {"host_lanes": 2}), ("three lanes", {"host_lanes": 3}), ("four lanes", {"host_lanes": 4}),
+         ("chunk 32 MiB", {"host_chunk_bytes": 32 << 20}), ("chunk 64 MiB", {"host_chunk_bytes": 64 << 20}),
+         ("chunk 128 MiB", {"host_chunk_bytes": 128 << 20}), ("chunk 256 MiB", {"host_chunk_bytes": 256 << 20}),
+         ("chunk 256 MiB, 2 lanes", {"host_chunk_bytes": 256 << 20, "host_lanes": 2}),
+         ("4 threads", {"host_threads": 4}), ("16 threads", {"host_threads": 16})]
 
 
 def main():
@@ -51,7 +52,7 @@ def main():
         print(f"{c}: device-resident {rec['device_resident_cw_per_s'] / 1e6:.3f} M cw/s")
         for r in rec["rows"]:
             print(f"  {r['setting']:42s} {r['llr']} {r['value'] / 1e6:8.3f} M cw/s ({r['ms']:7.2f} ms, {r['input_GBps']:5.1f} GB/s in) bound {r['bound_cw_per_s'] / 1e6:7.3f} M ({r['bound_by']}) "
-                  f"-> {r['frac_of_bound']:5.2f}  chunks {r['chunks']} x {r['chunk_codewords']} lanes {r['lanes']} threads {r['copy_threads']} ok={r['bits_equal_device_resident']}", flush=True)
+                  f"-> {r['frac_of_bound']:5.2f}  chunks {r['chunks']} x {r['chunk_codewords']} lanes {r['lanes']} threads {r['copy_threads']} ok={r['bits_equal_device_resident']} fresh-out {r['fresh_out_value'] / 1e6:.3f} M us {r['host_thread_us']}", flush=True)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(res, open(a.out, "w"), indent=1)
 
