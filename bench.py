@@ -399,7 +399,10 @@ def monte_carlo_leg(args, code, dist, dev, rank, world, engine=None, native=True
             out["native_multi"] = box.get("rec", {"error": "no record"})
             equal["native_multi"] = box.get("equal")
     hbar()
-    out["counters_equal_single_gpu"] = (None if not native else bool(equal["multiprocess"] and (equal["native_multi"] is not False)))
+    # true only when EVERY driver that was attempted compared equal (a native leg that raised or missed its deadline leaves
+    # None there: the combined flag is then None, never a pass)
+    out["counters_equal_single_gpu"] = (None if (not native or rank != 0 or equal["multiprocess"] is None or equal["native_multi"] is None)
+                                        else bool(equal["multiprocess"] and equal["native_multi"]))
     out["counters_equal_single_gpu_detail"] = dict(equal, prefix_trials=MC_PREFIX)
     return out
 

@@ -179,6 +179,7 @@ struct polar_code {
     // device
     bool dev_ready = false;
     int device = -1, num_cu = 0;
+    size_t lds_per_block = 0;        // hipDeviceAttributeMaxSharedMemoryPerBlock (160 KiB on gfx950): what the one-codeword-per-wave kernels are gated on
     DevBuf<uint8_t> d_frozen, d_crcm;
     DevBuf<uint16_t> d_order, d_info_rank;
     DevBuf<uint32_t> d_crc_mask, d_ctl, d_sc_ops, d_sc_lat_ops, d_var_scr;
@@ -447,6 +448,10 @@ int ensure_device(polar_code *h, DevGuard &dg) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, h->device));
     h->num_cu = prop.multiProcessorCount;
+    {
+        int v = 0;
+        h->lds_per_block = (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, h->device) == hipSuccess && v > 0) ? (size_t)v : (size_t)64 * 1024;
+    }
     int rc;
     if ((rc = upload(h->d_frozen, h->frozen))) return rc;
     if ((rc = upload(h->d_ctl, h->ctl))) return rc;
@@ -741,7 +746,8 @@ int polar_decode_scl_llr_batch_dev(polar_code_t *h, const double *d_llr, long B,
 
 // list size 1, small batches: one codeword per wave, whole state in LDS (sc_lat_kernel)
 static bool use_sc_lat(const polar_code_t *h, long B) {
-    return h->n <= polar_sc_lat_max_log() && h->knobs.lat_max_b >= 0 && B <= (h->knobs.lat_max_b ? h->knobs.lat_max_b : 2048);
+    return h->n <= polar_sc_lat_max_log() && polar_sc_lat_lds_bytes(h->N, (int)h->sc_lat_ops.size()) <= h->lds_per_block &&
+           h->knobs.lat_max_b >= 0 && B <= (h->knobs.lat_max_b ? h->knobs.lat_max_b : 2048);
 }
 // phase (list size 1 with the one-codeword-per-wave kernel only): 0 = everything; 1 = the decode kernel alone — the caller
 // looks at the flag words itself and runs phase 2 (work list + general kernel over the flagged codewords) only when one is
@@ -774,7 +780,7 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
     int lds_log = h->lds_log ? h->lds_log : (pipe ? 4 : 3);
     const int wpb = polar_decode_waves_per_block(pipe);
     const size_t lds = polar_decode_lds_bytes(lds_log, pipe);
-    const int max_blocks_by_lds = (int)((160 * 1024) / lds);
+    const int max_blocks_by_lds = (int)(h->lds_per_block / lds);
     if (max_blocks_by_lds < 1) return fail(POLAR_E_ARG, "lds_log %d does not fit the LDS", lds_log);
     if (wpc > max_blocks_by_lds * wpb) wpc = max_blocks_by_lds * wpb;
     long groups = (B + G - 1) / G;
@@ -886,7 +892,7 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
     // against 2.9 ms — so the latency form takes them unless mode 1 forces the LLR-domain arithmetic)
     const bool lat_ed = (gs == 2) ? (mode != 1) : ed;
     const size_t lat_lds = polar_decode_lat_lds_bytes(h->N, gs, h->W);
-    const long lat_resident = lat_lds <= (size_t)160 * 1024 ? (long)h->num_cu * std::min<long>(4, (long)(((size_t)160 * 1024) / lat_lds)) : 0;   // waves the LDS lets a device hold
+    const long lat_resident = lat_lds <= h->lds_per_block ? (long)h->num_cu * std::min<long>(4, (long)(h->lds_per_block / lat_lds)) : 0;   // waves the LDS lets a device hold
     const bool lat_list = (gs == 2 || (ed && (gs == 4 || gs == 8))) && h->knobs.lat_max_b >= 0 && lat_resident > 0 &&
                           B <= (h->knobs.lat_max_b ? h->knobs.lat_max_b : lat_resident);
     // (measured, N = 2048: L = 4 B = 1 ... 256 2.45 ... 2.59 ms against 3.87 ... 4.36 ms for the batch kernel, L = 2 2.9 ... 3.0 against
@@ -1357,12 +1363,18 @@ int polar_reserve(polar_code_t *h, long B, int L) {
     if (rc) return rc;
     DevBuf<double> llr, pm;
     DevBuf<uint8_t> out;
-    if ((rc = llr.ensure((size_t)B * h->N)) || (rc = out.ensure((size_t)B * h->K)) || (rc = pm.ensure((size_t)B))) { llr.release(); out.release(); pm.release(); return rc; }
+    if ((rc = llr.ensure((size_t)B * h->N + 1)) || (rc = out.ensure((size_t)B * h->K)) || (rc = pm.ensure((size_t)B))) { llr.release(); out.release(); pm.release(); return rc; }
     rc = polar_synth_llr_dev(h, 1, 0, B, polar_snr_sqrt_linear(h, 2.0), llr.p, nullptr, nullptr);
     const int top = std::min(pow2ceil(L), POLAR_MAX_LIST);
+    // every kernel family a call within (B, L) can reach: per list size the batch kernel at B and the one-codeword-per-wave
+    // kernel at one codeword (its flag / work-list buffers are its own: polar_reserve(B, 2) above the latency threshold used
+    // to leave them to the first small call), list size 1 also with a requested metric (the general kernel) and from rows
+    // that are NOT 16-byte aligned (the converted copy the in-place reads cannot serve)
     for (int l = 1; l <= top && !rc; l <<= 1) {
         rc = polar_decode_scl_llr_batch_dev(h, llr.p, B, l, out.p, nullptr, nullptr);
-        if (!rc && l == 1) rc = polar_decode_scl_llr_batch_dev(h, llr.p, B, l, out.p, pm.p, nullptr);   // (a requested metric: the general kernel)
+        if (!rc && l <= 8) rc = polar_decode_scl_llr_batch_dev(h, llr.p, 1, l, out.p, nullptr, nullptr);
+        if (!rc && l == 1) rc = polar_decode_scl_llr_batch_dev(h, llr.p, B, l, out.p, pm.p, nullptr);
+        if (!rc && l == 1) rc = polar_decode_scl_llr_batch_dev(h, llr.p + 1, B, l, out.p, nullptr, nullptr);
     }
     hipError_t e = hipDeviceSynchronize();
     llr.release(); out.release(); pm.release();
@@ -1820,7 +1832,7 @@ int bler_impl(polar_code_t *h, int constellation, const int *devices, int n_dev,
                 dup = true;
             }
     }
-    if (h->multi_poisoned) return fail(POLAR_E_DEVICE, "an earlier multi-device round of this handle never returned: the handle accepts no further multi-device calls");
+    if (h->multi_poisoned) return fail(POLAR_E_DEVICE, "an earlier multi-device round of this handle never returned: the handle accepts no further get_bler_quick calls");
     const bool want_rccl = (n_dev > 1 || h->knobs.force_rccl) && !h->knobs.no_rccl && !dup;
     if (h->multi && (h->multi->devs != devs || (want_rccl && !h->multi->rccl && g_rccl.load()))) multi_release(h, false);
     for (int d = 0; d < n_dev; ++d) {
@@ -1961,7 +1973,7 @@ int bler_impl(polar_code_t *h, int constellation, const int *devices, int n_dev,
         if (mc->timed_out) {
             rc_all = POLAR_E_DEVICE;
             err_msg = "a multi-device round exceeded the watchdog (" + std::to_string(h->knobs.multi_timeout_s) + " s): communicators aborted" +
-                      (mc->stuck ? "; a worker never returned, the handle accepts no further multi-device calls" : "");
+                      (mc->stuck ? "; a worker never returned, the handle accepts no further get_bler_quick calls" : "");
         }
         if (mc->stuck) break;                        // (the job's vectors may still be written by the worker that is stuck)
         // report the device that failed first-hand, not a peer that was merely told to stop

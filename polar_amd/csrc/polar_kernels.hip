@@ -1858,7 +1858,8 @@ static hipError_t launch_lat(const PolarDecodeParams &p, int blocks, hipStream_t
     const size_t lds = polar_decode_lat_lds_bytes(p.N, GS, p.W);
     // (per launch, not once per process: the attribute belongs to the function ON THE CURRENT DEVICE, and the multi-device Monte-Carlo
     // driver launches from one thread per device)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&scl_decode_llr_kernel<GS, 3, 1, ED, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scl_decode_llr_kernel<GS, 3, 1, ED, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;        // (the host checks `lds` against the device's limit before it chooses this kernel)
     hipLaunchKernelGGL((scl_decode_llr_kernel<GS, 3, 1, ED, 0, 1>), dim3(blocks), dim3(64), lds, st, p);
     return hipGetLastError();
 }

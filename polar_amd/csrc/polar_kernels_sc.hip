@@ -783,8 +783,11 @@ size_t polar_sc_lat_lds_bytes(int N, int n_ops) { return 324 * 8 + (size_t)2 * N
 int polar_sc_lat_max_log() { return 12; }       // 16 N bytes of LDS per wave: 64 KiB at N = 4096
 hipError_t polar_launch_sc_lat(const PolarScParams &p, int blocks, hipStream_t st) {
     const size_t lds = polar_sc_lat_lds_bytes(p.N, p.n_ops);
-    if (lds > 48 * 1024)          // (per launch: the attribute belongs to the function on the current device)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sc_lat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (lds > 48 * 1024) {        // (per launch: the attribute belongs to the function on the current device; the host only comes
+                                  // here when `lds` fits the device's limit — a refusal is an error, not something to launch through)
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sc_lat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(sc_lat_kernel, dim3(blocks), dim3(64), lds, st, p);
     return hipGetLastError();
 }

@@ -178,6 +178,67 @@ def test_a_failing_collective_enqueue_aborts_before_anyone_synchronises(built_li
     assert g.debug_get("comm_inits") == n0 + 1
 
 
+def test_a_round_that_takes_too_long_is_aborted_by_the_watchdog_and_the_next_call_works(built_lib):
+    """Worker 1 of three does not answer for 2.5 s in its second round (test hook "stall_device": a hang OUTSIDE every
+    collective — the watchdog of round 4 only covered hangs inside one, and its second wait had no bound). Watchdog 1 s:
+    step 1 raises the abort flag and aborts the host barrier — the two peers waiting there are released and report "round
+    aborted: watchdog" —, the sleeper wakes up inside the grace period, sees the flag, stays out of the reduction; the call
+    returns POLAR_E_DEVICE in about the stall time, nothing is leaked, the next call rebuilds the context and gives the
+    undisturbed counters. Then the same with ONE device through RCCL and a worker thread forced (force_workers): the
+    worker aborts its own communicator, the next call makes a new one."""
+    import time
+    import polar_amd
+    o, g = _pair(8, 128, 8)
+    g.debug_set("share_device", 1)
+    args = dict(max_runs=900, max_err=10**6, seed=3, batch=300)
+    want = g.get_bler_quick([1.0], [1, 4], devices=[0, 0, 0], **args)
+    g.debug_set("multi_timeout_s", 1); g.debug_set("multi_grace_s", 10)
+    g.debug_set("stall_device", 1); g.debug_set("stall_ms", 2500)
+    t = time.perf_counter()
+    with pytest.raises(polar_amd.PolarError, match="exceeded the watchdog"):
+        g.get_bler_quick([1.0], [1, 4], devices=[0, 0, 0], **args)
+    dt = time.perf_counter() - t
+    assert 2.0 < dt < 6.0 and g.debug_get("multi_poisoned") == 0
+    g.debug_set("stall_device", -1)
+    assert np.array_equal(np.asarray(g.get_bler_quick([1.0], [1, 4], devices=[0, 0, 0], **args)), np.asarray(want))
+    # one device, RCCL, a worker thread of its own
+    g.debug_set("share_device", 0); g.debug_set("force_rccl", 1); g.debug_set("force_workers", 1)
+    one = g.get_bler_quick([1.0], [1, 4], devices=[0], **args)
+    assert g.last_used_rccl and np.array_equal(np.asarray(one), np.asarray(want)) and g.debug_get("worker_threads_started") >= 1
+    n0 = g.debug_get("comm_inits")
+    g.debug_set("stall_device", 0)
+    with pytest.raises(polar_amd.PolarError, match="exceeded the watchdog"):
+        g.get_bler_quick([1.0], [1, 4], devices=[0], **args)
+    g.debug_set("stall_device", -1)
+    two = g.get_bler_quick([1.0], [1, 4], devices=[0], **args)
+    assert g.last_used_rccl and np.array_equal(np.asarray(two), np.asarray(want)) and g.debug_get("comm_inits") == n0 + 1
+
+
+def test_a_worker_that_never_answers_costs_the_handle_not_the_caller(built_lib):
+    """The stall outlasts the watchdog AND both grace periods (1 s each): the call still returns — after about three seconds,
+    with the error — instead of waiting for ever (round 4: unbounded second wait), the handle refuses further Monte-Carlo
+    calls and frees nothing (a thread that does not come back from the driver cannot be cancelled: what it may still touch is
+    leaked on purpose), and decoding through the handle still works."""
+    import time
+    import polar_amd
+    o, g = _pair(8, 128, 8)
+    g.debug_set("share_device", 1)
+    args = dict(max_runs=900, max_err=10**6, seed=3, batch=300)
+    g.get_bler_quick([1.0], [1, 4], devices=[0, 0], **args)
+    g.debug_set("multi_timeout_s", 1); g.debug_set("multi_grace_s", 1)
+    g.debug_set("stall_device", 1); g.debug_set("stall_ms", 6000)
+    t = time.perf_counter()
+    with pytest.raises(polar_amd.PolarError, match="never returned"):
+        g.get_bler_quick([1.0], [1, 4], devices=[0, 0], **args)
+    assert time.perf_counter() - t < 5.0 and g.debug_get("multi_poisoned") == 1
+    with pytest.raises(polar_amd.PolarError, match="never returned"):
+        g.get_bler_quick([1.0], [1], **args)
+    llr, _ = o.synth_llr(5, 0, 16, o.snr_sqrt_linear(2.0))
+    assert (g.decode_scl_llr(llr, 4) == o.decode_scl_llr(llr, 4)).all()
+    time.sleep(4.0)              # (let the sleeper finish its round on the leaked context before the process goes on)
+    g.close()
+
+
 def test_worker_threads_live_on_the_handle_between_calls(built_lib):
     """One thread per device, created with the device list's context and parked between rounds and calls (round 3 created
     and joined n_dev threads per ROUND)."""

@@ -533,6 +533,28 @@ def test_reserve_means_no_allocation_inside_the_asynchronous_calls(built_lib, or
     assert g.debug_get("allocs") > a0
 
 
+@pytest.mark.parametrize("Lr", [1, 2])
+def test_reserve_covers_the_latency_kernels_and_misaligned_rows(built_lib, oracle_built, Lr):
+    """polar_reserve(B, 2) with B above the latency threshold ran only the batch kernel of the 2-lane groups; the first SMALL call
+    then took the one-codeword-per-wave kernel and allocated its flag and work-list buffers inside the asynchronous call — and
+    so did a list-size-1 call from rows that are not 16-byte aligned (the converted copy). Both are part of the reservation now."""
+    import torch
+    o, g = _pair(11, 1024, 16)
+    B = 4096
+    g.reserve(B, Lr)
+    llr = torch.empty(B * 2048 + 1, dtype=torch.float64, device="cuda")
+    g.synth_llr_dev(3, 0, B, g.snr_sqrt_linear(2.0), llr.data_ptr())
+    out = torch.empty((B, 1024), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    a0 = g.debug_get("allocs")
+    for L in range(1, Lr + 1):
+        for b in (1, 3, 200, B):
+            g.decode_scl_llr_dev(llr.data_ptr(), b, L, out.data_ptr())
+    g.decode_scl_llr_dev(llr.data_ptr() + 8, B, 1, out.data_ptr())          # 8-byte aligned only
+    torch.cuda.synchronize()
+    assert g.debug_get("allocs") == a0
+
+
 def test_list_size_one_accepts_rows_that_are_not_16_byte_aligned(built_lib, oracle_built):
     """The in-place channel reads of the list-size-1 kernel are 16-byte vector loads; a caller's pointer with only the
     natural alignment of its element type (a view into a larger buffer, offset by one double / one float) is decoded through
