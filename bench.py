@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="codewords for the CPU baseline (-1 = auto, 0 = skip)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short timings of BASELINE.json configs 1, 2, 3, 5")
     ap.add_argument("--only-config", default="", help="run ONE of the other configurations (" + ", ".join(OTHER_CONFIGS) + ") and print its record: the command tools/profile_configs.sh profiles")
-    ap.add_argument("--mc-trials", type=int, default=4194304, help="total trials of the end-to-end get_bler_quick leg (0 = skip)")
+    ap.add_argument("--mc-trials", type=int, default=16777216, help="total trials of the end-to-end get_bler_quick leg, strong scaling (0 = skip): 64 rounds of 262144 at one GPU, 8 full rounds per GPU at eight")
     ap.add_argument("--dry-run-gloo", action="store_true",
                     help="launcher / rendezvous / counter all-reduce only, on CPU over gloo: no kernel runs, the line carries "
                          "\"dry_run\": true and no throughput (tests/test_bench_launcher.py)")
@@ -313,6 +313,7 @@ def monte_carlo_leg(args, code, dist, dev, rank, world, engine=None, native=True
     Ls = [args.L]
     total, per_round = args.mc_trials, 262144 * world
     no_stop = 10 ** 12
+    use_ranks = engine is None              # the real engine: the library's own driver per rank; stand-in engines: the step-wise loop
     if engine is None:
         engine = code.mc_batch
 
@@ -341,20 +342,39 @@ def monte_carlo_leg(args, code, dist, dev, rank, world, engine=None, native=True
                        f"{total} trials in total (strong scaling), rounds of 262144 trials per GPU, one counter all-reduce per round, "
                        f"generation + encoding + channel + decode + counting on the device",
            "total_trials": total, "n_gpus": world}
-    # ---- multi-process driver (this launch: one rank per GPU)
-    get_bler_quick_sharded(engine, MC_GRID, Ls, max_runs=min(total, per_round), max_err=no_stop, seed=args.seed, global_batch=per_round, device=red_dev)   # warm-up (allocations)
+    # ---- multi-process driver (this launch: one rank per GPU): the library's own driver per rank (pipelined rounds), the
+    # counters summed by one torch.distributed all-reduce per step; stand-in engines (dry run) keep the step-wise loop
+    from polar_amd.montecarlo import get_bler_quick_ranks
+    if use_ranks:
+        def sharded(max_runs, global_batch, stats=None):
+            return get_bler_quick_ranks(code, MC_GRID, Ls, max_runs=max_runs, max_err=no_stop, seed=args.seed, global_batch=global_batch, device=red_dev, stats=stats)
+        drv = "polar_get_bler_quick_rank per rank (polar_amd/montecarlo.py get_bler_quick_ranks): rounds pipelined on the device, one torch.distributed all-reduce per step"
+    else:
+        def sharded(max_runs, global_batch, stats=None):
+            return get_bler_quick_sharded(engine, MC_GRID, Ls, max_runs=max_runs, max_err=no_stop, seed=args.seed, global_batch=global_batch, device=red_dev, stats=stats)
+        drv = "polar_amd/montecarlo.py get_bler_quick_sharded, one rank per GPU, torch.distributed all-reduce per round"
+    sharded(min(total, per_round), per_round)           # warm-up (allocations)
     sync(); hbar()
     st = {}
     t0 = time.perf_counter()
-    bler, err, run = get_bler_quick_sharded(engine, MC_GRID, Ls, max_runs=total, max_err=no_stop, seed=args.seed, global_batch=per_round, device=red_dev, stats=st)
+    bler, err, run = sharded(total, per_round, st)
     sync(); hbar()
     dt = tmax(time.perf_counter() - t0)
-    out["multiprocess"] = {"driver": "polar_amd/montecarlo.py, one rank per GPU, torch.distributed all-reduce per round",
-                           "seconds": dt, "mc_trials_per_s": total / dt, "rounds": st.get("rounds"),
+    out["multiprocess"] = {"driver": drv, "seconds": dt, "mc_trials_per_s": total / dt, "rounds": st.get("rounds"), "steps": st.get("steps"),
+                           "step_ms": {k: st.get("step_ms_" + k) for k in ("first", "min", "median", "max")},
                            "bler": [float(x) for x in bler[0]], "block_errors": [int(x) for x in err[0]], "runs": [int(x) for x in run[0]]}
     out["mc_trials_per_s"] = total / dt
+    # weak scaling beside it: a fixed 8 rounds of 262144 trials PER GPU
+    weak_total = 8 * per_round
+    sync(); hbar()
+    t0 = time.perf_counter()
+    sharded(weak_total, per_round)
+    sync(); hbar()
+    dtw = tmax(time.perf_counter() - t0)
+    out["mc_weak"] = {"trials": weak_total, "rounds_per_gpu": 8, "seconds": dtw, "mc_trials_per_s": weak_total / dtw,
+                      "note": "the same sweep with 8 rounds of 262144 trials per GPU whatever the world size"}
     # ---- the same 65536-trial prefix: sharded over the ranks vs ONE GPU alone (rank 0)
-    _, e_sh, r_sh = get_bler_quick_sharded(engine, MC_GRID, Ls, max_runs=MC_PREFIX, max_err=no_stop, seed=args.seed, global_batch=MC_PREFIX, device=red_dev)
+    _, e_sh, r_sh = sharded(MC_PREFIX, MC_PREFIX)
     equal = {"multiprocess": None, "native_multi": None}
     e_one = r_one = None
     if rank == 0 and native:
@@ -378,9 +398,10 @@ def monte_carlo_leg(args, code, dist, dev, rank, world, engine=None, native=True
                 dt2 = time.perf_counter() - t0
                 _, c3 = code.get_bler_quick(MC_GRID, Ls, max_runs=MC_PREFIX, max_err=no_stop, seed=args.seed, batch=MC_PREFIX, devices=devs, return_counters=True)
                 box["equal"] = bool(np.array_equal(e_one, c3["err"]) and np.array_equal(r_one, c3["run"]))
-                box["rec"] = {"driver": "polar_get_bler_quick_multi_ex from rank 0: one worker thread, stream and table clone per GPU, "
-                                        "ncclAllReduce(uint64, sum) per round" + ("" if code.last_used_rccl else " (host-side sum: RCCL not used)"),
+                box["rec"] = {"driver": "polar_get_bler_quick_multi_ex from rank 0: one worker thread, stream and table clone per GPU, rounds pipelined, "
+                                        "ncclAllReduce(uint64, sum) per step" + ("" if code.last_used_rccl else " (host-side sum: RCCL not used)"),
                               "seconds": dt2, "mc_trials_per_s": total / dt2, "rounds": c2["rounds"], "used_rccl": bool(code.last_used_rccl),
+                              "step_ms": {k: code.debug_get("round_us_" + k) / 1e3 for k in ("first", "min", "median", "max")},
                               "bler": [float(x) for x in b2[0]], "block_errors": [int(x) for x in c2["err"][0]],
                               "equals_multiprocess_counters": bool(np.array_equal(c2["err"], err) and np.array_equal(c2["run"], run))}
             except Exception as ex:                              # (the headline above must be printed whatever happens here)

@@ -187,6 +187,16 @@ int polar_get_bler_quick_multi_ex(polar_code_t *h, int constellation, const int 
                                   double *bler_out, double *ber_out, uint64_t *err_out, uint64_t *run_out, long *rounds_out,
                                   int *used_rccl);
 
+/* The same sweep with the trials shared by `world` PROCESSES (one per GPU, as a process-group or MPI launcher starts them): this process is
+ * `rank`, its handle's device simulates the trials rank, rank + world, ... of every round, and after every step `reduce` is
+ * called — collectively, on every rank, the same number of times — to SUM the n uint64 counters in place over the ranks
+ * (e.g. an all-reduce of the process group; return non-zero to fail the call). Counters, estimates and rounds are those of
+ * polar_get_bler_quick_multi_ex with world devices. polar_amd/montecarlo.py drives it with its process group's all-reduce. */
+typedef int (*polar_reduce_fn)(void *user, uint64_t *counters, int n);
+int polar_get_bler_quick_rank(polar_code_t *h, int constellation, int rank, int world, polar_reduce_fn reduce, void *user,
+                              const double *axis, int n_e, const uint8_t *L, int n_L, long max_runs, long max_err, uint64_t seed,
+                              long batch, double *bler_out, double *ber_out, uint64_t *err_out, uint64_t *run_out, long *rounds_out);
+
 /* test hook: number of ncclCommInitAll calls made by this library so far (the communicators and streams of a device
  * list are cached on the handle: a second polar_get_bler_quick_multi with the same list makes none). When a device's
  * round fails, no device enters the round's collective, the communicators are aborted and the call returns the error. */

@@ -426,6 +426,38 @@ class PolarCode:
             res = res + ({"err": err, "run": run, "rounds": int(rounds.value)},)
         return res[0] if len(res) == 1 else res
 
+    def get_bler_quick_rank(self, ebno_vec, list_size_vec, rank, world, reduce, max_runs=1000, max_err=100, seed=1, batch=None,
+                            constellation=None):
+        """polar_get_bler_quick_rank: this process is `rank` of `world` sharing the sweep; `reduce(a)` must SUM the uint64 numpy
+        array `a` in place over the ranks (called collectively after every step). Returns (bler, ber, counters) like
+        get_bler_quick(..., return_ber=True, return_counters=True)."""
+        ebno = np.ascontiguousarray(ebno_vec, np.float64)
+        Ls = np.ascontiguousarray(list_size_vec, np.uint8)
+        shape = (len(Ls), len(ebno))
+        out, ber = np.zeros(shape, np.float64), np.zeros(shape, np.float64)
+        err, run = np.zeros(shape, np.uint64), np.zeros(shape, np.uint64)
+        rounds = C.c_long(0)
+        failure = []
+
+        @C.CFUNCTYPE(C.c_int, C.c_void_p, _u64p, C.c_int)
+        def cb(_user, ptr, n):
+            try:
+                a = np.ctypeslib.as_array(ptr, shape=(n,))
+                reduce(a)
+                return 0
+            except Exception as ex:          # (no exception may cross the C frames)
+                failure.append(ex)
+                return 1
+        cid = 0 if constellation is None else _constellation_id(constellation)
+        rc = lib().polar_get_bler_quick_rank(self._h, C.c_int(cid), C.c_int(rank), C.c_int(world), cb, None,
+                                             _p(ebno, _dp), C.c_int(len(ebno)), _p(Ls, _u8p), C.c_int(len(Ls)),
+                                             C.c_long(max_runs), C.c_long(max_err), C.c_uint64(seed), C.c_long(batch or 0),
+                                             _p(out, _dp), _p(ber, _dp), _p(err, _u64p), _p(run, _u64p), C.byref(rounds))
+        if failure:
+            raise failure[0]
+        _check(rc)
+        return out, ber, {"err": err, "run": run, "rounds": int(rounds.value), "steps": self.debug_get("round_us_count")}
+
 
 # ---- Monte-Carlo code construction (PolarM/PolarCode.m:95-196) ---------------------------------
 def _num2str(x):

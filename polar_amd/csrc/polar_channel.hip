@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64) void mc_count_compact_kernel(const uint8_t *dec
                                                                const uint64_t *alive_in, const unsigned *n_in, uint64_t *alive_out,
                                                                unsigned *n_out, unsigned long long *ctr) {
     const int lane = threadIdx.x;
-    if ((long)*n_in < B) B = (long)*n_in;
+    if (n_in && (long)*n_in < B) B = (long)*n_in;          // (n_in == nullptr: exactly B rows)
     for (long c = blockIdx.x; c < B; c += gridDim.x) {
         unsigned nd = 0;
         for (int i = lane; i < K; i += 64) nd += (dec[(size_t)c * K + i] != sent[(size_t)c * K + i]) ? 1u : 0u;

@@ -229,6 +229,12 @@ struct polar_code {
     DevBuf<uint64_t> d_alive[2];
     DevBuf<unsigned int> d_nalive;           // [2]
     DevBuf<unsigned long long> d_mc_ctr;     // [n_L*n_e][2]: block errors, bit errors of the round
+    // pipelined rounds (mc_step_launch): the alive lists of the rounds in flight — slot (list size, round mod slots), double-buffered —,
+    // the lengths the device wrote, and their host copy
+    struct McSlot { DevBuf<uint64_t> list[2]; int cur = 0; long cnt = 0; };
+    std::vector<McSlot> mc_slots;
+    DevBuf<unsigned int> d_slot_n;
+    std::vector<unsigned int> h_slot_n;
     // per-device clones for polar_get_bler_quick_multi (owned by this handle)
     std::vector<polar_code *> clones;
     // streams + RCCL communicators of the last multi-device call, kept for the next one with the same device list
@@ -591,6 +597,8 @@ void polar_destroy(polar_code_t *h) {
     h->d_counter.release(); h->d_sel.release(); h->d_work.release();
     h->d_ech.release(); h->d_flags.release(); h->d_list.release(); h->d_count.release();
     h->d_alive[0].release(); h->d_alive[1].release(); h->d_nalive.release(); h->d_mc_ctr.release();
+    for (auto &sl : h->mc_slots) { sl.list[0].release(); sl.list[1].release(); }
+    h->d_slot_n.release();
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     h->d_sc_ops.release(); h->d_sc_lat_ops.release(); h->d_flag_words.release(); h->d_var_scr.release(); h->d_tab_scr.release();
@@ -678,9 +686,10 @@ long polar_debug_get(const polar_code_t *h, const char *key) {
     if (s == "last_rounds") return h->last_rounds;
     if (s == "last_round_max_per_device") return h->last_round_max_per_device;
     if (s == "worker_threads_started") return h->worker_threads_started;
-    if (s.compare(0, 9, "round_us_") == 0) {
+    if (s.compare(0, 9, "round_us_") == 0) {        // wall time of the steps of the last get_bler_quick* call
         if (h->round_us.empty()) return 0;
         std::vector<long> v(h->round_us);
+        if (s == "round_us_count") return (long)v.size();
         if (s == "round_us_first") return v.front();
         std::sort(v.begin(), v.end());
         if (s == "round_us_min") return v.front();
@@ -1466,6 +1475,85 @@ static int mc_round_collect(polar_code_t *h, long T, int P, const uint8_t *enabl
     return POLAR_OK;
 }
 
+// ---- pipelined rounds (round 5) -------------------------------------------------------------------------------------
+// Within a round the Eb/N0 points depend on each other (a point simulates the trials that FAILED at the point before:
+// PolarCode.cpp:728-742), and beyond the first they are small — 41 000 / 9 600 / 1 400 / 150 of 262 144 trials on BASELINE
+// configuration 4's grid — while a launch of the list kernels takes a wave-decode (8 ms at L = 32) however little it carries:
+// four under-filled launches with a tail each per round. ACROSS rounds nothing depends on anything, so a step decodes, per
+// list size, ONE merged batch: point 1 of the newest round, point 2 of the round before, point 3 of the one before that, ...
+// (each stage generated at its own Eb/N0 into its rows of the batch, counted and compacted from them afterwards). The
+// host-side schedule (bler_impl) keeps the reference's per-round semantics exactly: whether round r simulates point i is
+// decided from point i's errors in the rounds before r, which have all passed point i by then.
+struct McStage { int li, ie, slot; long T; uint64_t base; bool fresh; };
+
+static int mc_step_launch(polar_code_t *h, int constellation, uint64_t seed, const std::vector<McStage> &stages, int part, int parts,
+                          const double *axis, int n_e, const uint8_t *Ls, int n_L, int n_slots, hipStream_t st) {
+    const int N = h->N, K = h->K, P = n_e * n_L;
+    int rc;
+    if ((rc = h->d_mc_ctr.ensure((size_t)2 * P))) return rc;
+    HIP_TRY(hipMemsetAsync(h->d_mc_ctr.p, 0, (size_t)2 * P * sizeof(unsigned long long), st));
+    if ((int)h->mc_slots.size() < n_L * n_slots) h->mc_slots.resize((size_t)n_L * n_slots);
+    if ((rc = h->d_slot_n.ensure((size_t)n_L * n_slots))) return rc;
+    h->h_slot_n.resize((size_t)n_L * n_slots);
+    for (int li = 0; li < n_L; ++li) {
+        long rows = 0;
+        for (const McStage &s : stages) {
+            if (s.li != li) continue;
+            polar_code::McSlot &sl = h->mc_slots[(size_t)li * n_slots + s.slot];
+            if (s.fresh) sl.cnt = (s.T - part + parts - 1) / parts;          // this device's trials of the round: base + part, + parts, ...
+            rows += sl.cnt;
+        }
+        if (rows == 0) continue;
+        if ((rc = h->d_in.ensure((size_t)rows * N))) return rc;
+        if ((rc = h->d_out.ensure((size_t)rows * K))) return rc;
+        if ((rc = h->d_bytes_a.ensure((size_t)rows * K))) return rc;      // sent info
+        long off = 0;
+        for (const McStage &s : stages) {
+            if (s.li != li) continue;
+            const size_t id = (size_t)li * n_slots + s.slot;
+            polar_code::McSlot &sl = h->mc_slots[id];
+            if (sl.cnt == 0) continue;
+            if (s.fresh) {
+                if ((rc = sl.list[0].ensure((size_t)sl.cnt)) || (rc = sl.list[1].ensure((size_t)sl.cnt))) return rc;
+                sl.cur = 0;
+                HIP_TRY(polar_launch_mc_init_alive(sl.list[0].p, h->d_slot_n.p + id, s.base + (uint64_t)part, parts, sl.cnt, st));
+            }
+            PolarEncodeParams p;
+            fill_enc(h, p);
+            p.B = sl.cnt; p.seed = seed; p.sel = sl.list[sl.cur].p; p.n_dev = nullptr;
+            fill_channel(h, p, constellation, axis[s.ie]);
+            p.llr = h->d_in.p + (size_t)off * N; p.info_out = h->d_bytes_a.p + (size_t)off * K;
+            HIP_TRY(polar_launch_synth(p, st));
+            off += sl.cnt;
+        }
+        if ((rc = decode_impl(h, h->d_in.p, 0, rows, nullptr, Ls[li], h->d_out.p, nullptr, st, nullptr, nullptr))) return rc;
+        off = 0;
+        for (const McStage &s : stages) {
+            if (s.li != li) continue;
+            const size_t id = (size_t)li * n_slots + s.slot;
+            polar_code::McSlot &sl = h->mc_slots[id];
+            if (sl.cnt == 0) continue;
+            HIP_TRY(hipMemsetAsync(h->d_slot_n.p + id, 0, sizeof(unsigned int), st));
+            HIP_TRY(polar_launch_mc_count_compact(h->d_out.p + (size_t)off * K, h->d_bytes_a.p + (size_t)off * K, sl.cnt, K, sl.list[sl.cur].p, nullptr,
+                                                  sl.list[sl.cur ^ 1].p, h->d_slot_n.p + id, h->d_mc_ctr.p + 2 * (size_t)(li * n_e + s.ie), st));
+            off += sl.cnt;
+        }
+    }
+    // the new list lengths come back with the counters (bler_impl: mc_step_finish after the stream is done)
+    HIP_TRY(hipMemcpyAsync(h->h_slot_n.data(), h->d_slot_n.p, h->h_slot_n.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    return POLAR_OK;
+}
+// after the step's stream work is done: the stages' lists are the failures now
+static void mc_step_finish(polar_code_t *h, const std::vector<McStage> &stages, int n_slots) {
+    for (const McStage &s : stages) {
+        const size_t id = (size_t)s.li * n_slots + s.slot;
+        polar_code::McSlot &sl = h->mc_slots[id];
+        if (sl.cnt == 0) continue;
+        sl.cnt = (long)h->h_slot_n[id];
+        sl.cur ^= 1;
+    }
+}
+
 static int mc_batch_impl(polar_code_t *h, int constellation, uint64_t seed, uint64_t t0, long T, long stride,
                          const double *ebno, int n_e, const uint8_t *Ls, int n_L,
                          const uint8_t *enabled, uint64_t *err, uint64_t *bit_err, uint64_t *run) {
@@ -1798,11 +1886,14 @@ long next_round(long batch, long max_err, long done, long max_runs, int n_dev) {
     return std::min(T, max_runs - done);
 }
 
+// rank / world / reduce: this process is one of `world` that share the sweep (polar_get_bler_quick_rank): its devices take the
+// partitions rank * n_dev + d of world * n_dev, and after every step `reduce` sums the step's counters over the processes
 int bler_impl(polar_code_t *h, int constellation, const int *devices, int n_dev, const double *ebno, int n_e, const uint8_t *Ls, int n_L,
               long max_runs, long max_err, uint64_t seed, long batch, double *bler_out, double *ber_out,
-              uint64_t *err_out, uint64_t *run_out, int *used_rccl) {
+              uint64_t *err_out, uint64_t *run_out, int *used_rccl, int rank = 0, int world = 1, polar_reduce_fn reduce = nullptr, void *reduce_user = nullptr) {
     if (!h || !ebno || !Ls || !bler_out) return fail(POLAR_E_ARG, "NULL argument");
     if (n_e <= 0 || n_L <= 0 || max_runs <= 0 || batch < 0 || n_dev < 1) return fail(POLAR_E_ARG, "bad sizes");
+    if (world < 1 || rank < 0 || rank >= world || (world > 1 && !reduce)) return fail(POLAR_E_ARG, "bad rank / world / reduce");
     if (constellation == POLAR_CONST_BPSK) constellation = 0;
     if (constellation != 0 && (constellation < POLAR_CONST_ASK4_GRAY || constellation > POLAR_CONST_ASK16_GRAY))
         return fail(POLAR_E_ARG, "unknown constellation %d", constellation);
@@ -1810,7 +1901,6 @@ int bler_impl(polar_code_t *h, int constellation, const int *devices, int n_dev,
         if (Ls[i] < 1 || Ls[i] > POLAR_MAX_LIST) return fail(POLAR_E_ARG, "list size %d out of range", (int)Ls[i]);
     const int P = n_e * n_L;
     std::vector<uint64_t> err(P, 0), bit(P, 0), run(P, 0);
-    std::vector<uint8_t> en(P, 1);
     DevGuard dg_;
     (void)hipGetDevice(&dg_.prev);
     // one context (clone of the tables + scratch) per device; streams, communicators and worker threads live on the
@@ -1883,32 +1973,33 @@ int bler_impl(polar_code_t *h, int constellation, const int *devices, int n_dev,
     std::string err_msg;
     h->last_rounds = 0; h->last_round_max_per_device = 0;
     h->round_us.clear();
-    // Everything a worker touches during a round lives in ONE shared object that the job holds by value: a worker the
+    // Everything a worker touches during a step lives in ONE shared object that the job holds by value: a worker the
     // watchdog had to give up on (MultiCtx::run_all step 3) may wake up after this function has returned.
     struct Job {
-        int n_dev, P, n_e, n_L, constellation, fail_dev, fail_coll, stall_dev;
+        int n_dev, P, n_e, n_L, n_slots, constellation, fail_dev, fail_coll, stall_dev, part0, parts;
         long stall_ms;
         uint64_t seed;
         bool rccl;
         MultiCtx *mc;
         std::vector<polar_code *> ctx;
         std::vector<double> axis;
-        std::vector<uint8_t> Ls, en;
+        std::vector<uint8_t> Ls;
+        std::vector<McStage> stages;
         std::vector<int> rcs;
         std::vector<std::string> msgs;
-        std::vector<long> Td;
         std::vector<std::vector<unsigned long long>> host_ctr;
-        long T = 0, done = 0;
-        int round_no = 0;
+        int step_no = 0;
         std::atomic<int> n_failed{0}, n_failed_coll{0};
     };
+    const int n_slots = n_e + 1, parts = world * n_dev;
     auto job = std::make_shared<Job>();
-    job->n_dev = n_dev; job->P = P; job->n_e = n_e; job->n_L = n_L; job->constellation = constellation;
+    job->n_dev = n_dev; job->P = P; job->n_e = n_e; job->n_L = n_L; job->n_slots = n_slots; job->constellation = constellation;
     job->fail_dev = h->knobs.fail_device; job->fail_coll = h->knobs.fail_collective;       // (test hooks)
     job->stall_dev = h->knobs.stall_device; job->stall_ms = h->knobs.stall_ms;
+    job->part0 = rank * n_dev; job->parts = parts;
     job->seed = seed; job->rccl = rccl; job->mc = mc; job->ctx = ctx;
-    job->axis.assign(ebno, ebno + n_e); job->Ls.assign(Ls, Ls + n_L); job->en.assign(P, 1);
-    job->rcs.assign(n_dev, POLAR_OK); job->msgs.assign(n_dev, std::string()); job->Td.assign(n_dev, 0);
+    job->axis.assign(ebno, ebno + n_e); job->Ls.assign(Ls, Ls + n_L);
+    job->rcs.assign(n_dev, POLAR_OK); job->msgs.assign(n_dev, std::string());
     job->host_ctr.assign(n_dev, std::vector<unsigned long long>((size_t)2 * P, 0));
     auto worker = [job](int d) {
         Job &J = *job;
@@ -1916,34 +2007,30 @@ int bler_impl(polar_code_t *h, int constellation, const int *devices, int n_dev,
         polar_code *c = J.ctx[d];
         const int n_dev = J.n_dev, P = J.P;
         hipStream_t st = mc->streams[d];
-        J.Td[d] = (J.T - d + n_dev - 1) / n_dev;
         int rc = POLAR_OK;
         std::string msg;
         if (hipSetDevice(c->device) != hipSuccess) { rc = POLAR_E_DEVICE; msg = "hipSetDevice failed"; }
-        else if (d == J.fail_dev && J.round_no == 1) { rc = POLAR_E_DEVICE; msg = "injected failure (fail_device)"; }
+        else if (d == J.fail_dev && J.step_no == 1) { rc = POLAR_E_DEVICE; msg = "injected failure (fail_device)"; }
         else {
-            // (test hook: this worker does not answer for stall_ms in its second round — a hang outside every collective)
-            if (d == J.stall_dev && J.round_no == 1) std::this_thread::sleep_for(std::chrono::milliseconds(J.stall_ms));
-            if (J.Td[d] > 0)
-                rc = mc_round_launch(c, J.constellation, J.seed, (uint64_t)(J.done + d), J.Td[d], n_dev, J.axis.data(), J.n_e, J.Ls.data(), J.n_L, J.en.data(), st);
-            else
-                rc = (c->d_mc_ctr.ensure((size_t)2 * P) || hipMemsetAsync(c->d_mc_ctr.p, 0, (size_t)2 * P * 8, st) != hipSuccess) ? POLAR_E_DEVICE : POLAR_OK;
+            // (test hook: this worker does not answer for stall_ms in its second step — a hang outside every collective)
+            if (d == J.stall_dev && J.step_no == 1) std::this_thread::sleep_for(std::chrono::milliseconds(J.stall_ms));
+            rc = mc_step_launch(c, J.constellation, J.seed, J.stages, J.part0 + d, J.parts, J.axis.data(), J.n_e, J.Ls.data(), J.n_L, J.n_slots, st);
             if (rc) msg = polar_last_error();
         }
         // (1) every worker learns whether ALL of them got this far: either every one enters the collective or none does
         // (a lone rank skipping it would leave the others blocked in it for good)
         if (rc) ++J.n_failed;
         const bool met = n_dev > 1 ? mc->bar->wait() : true;        // false: the watchdog aborted the barrier
-        const bool round_ok = met && J.n_failed.load() == 0 && !mc->abort_req.load();
-        if (round_ok) {
-            // sum of the round's counters over the devices (xGMI), in place on every device
+        const bool step_ok = met && J.n_failed.load() == 0 && !mc->abort_req.load();
+        if (step_ok) {
+            // sum of the step's counters over the devices (xGMI), in place on every device
             bool coll_failed = false;
-            if (d == J.fail_coll && J.round_no == 1) coll_failed = true;       // (test hook: the enqueue "fails" on this rank only)
+            if (d == J.fail_coll && J.step_no == 1) coll_failed = true;       // (test hook: the enqueue "fails" on this rank only)
             else if (J.rccl) {
                 void *comm = mc->get_comm(d);
                 if (!comm || g_rccl.AllReduce(c->d_mc_ctr.p, c->d_mc_ctr.p, (size_t)2 * P, kNcclUint64, kNcclSum, comm, st) != 0) coll_failed = true;
             }
-            if (coll_failed) { rc = POLAR_E_DEVICE; msg = (d == J.fail_coll && J.round_no == 1) ? "injected failure (fail_collective)" : "ncclAllReduce failed"; ++J.n_failed_coll; }
+            if (coll_failed) { rc = POLAR_E_DEVICE; msg = (d == J.fail_coll && J.step_no == 1) ? "injected failure (fail_collective)" : "ncclAllReduce failed"; ++J.n_failed_coll; }
             // (2) a rank whose enqueue failed AFTER the first barrier would leave its peers blocked behind a collective that
             // never completes: everybody meets again, and when any enqueue failed (or the watchdog fired) every rank aborts
             // its OWN communicator BEFORE it waits for its stream
@@ -1956,22 +2043,61 @@ int bler_impl(polar_code_t *h, int constellation, const int *devices, int n_dev,
             }
         } else if (!rc) { rc = POLAR_E_DEVICE; msg = (met && !mc->abort_req.load()) ? "round aborted: another device failed" : "round aborted: watchdog"; }
         if (mc->wait_stream(d) != hipSuccess && !rc) { rc = POLAR_E_DEVICE; msg = "stream synchronize failed"; }
+        if (!rc) mc_step_finish(c, J.stages, J.n_slots);
         J.rcs[d] = rc; J.msgs[d] = msg;
     };
-    for (long done = 0; done < max_runs;) {
+    // The schedule (see mc_step_launch): rounds in flight, oldest first; per list size each round has a next point `pend`. In a
+    // step every round simulates, per list size, its first ENABLED point in [pend, pend of the round before it at the start
+    // of the step) — never overtaking the round before it, so that when round r decides on point i (enabled iff point i's
+    // errors so far are <= max_err, PolarCode.cpp:725) every round before r has passed point i and no later round has touched
+    // it: the decision, the trials simulated and the run counts are exactly those of the reference's round-after-round loop.
+    struct PipeRound { long T; uint64_t base; int slot; std::vector<int> pend; std::vector<uint8_t> fresh; };
+    std::vector<PipeRound> inflight;
+    long done = 0, round_index = 0;
+    std::vector<unsigned long long> tot((size_t)2 * P);
+    for (;;) {
         bool any = false;
-        for (int i = 0; i < P; ++i) { en[i] = (err[i] <= (uint64_t)max_err); any |= en[i]; }   // :725
-        if (!any) break;
-        const long T = next_round(batch, max_err, done, max_runs, n_dev);      // trials of this round, all devices together
-        // device d simulates the trials done + d, done + d + n_dev, ... (counter-based inputs: the union does not
-        // depend on n_dev)
-        job->en = en; job->T = T; job->done = done;
+        for (int i = 0; i < P; ++i) any |= (err[i] <= (uint64_t)max_err);                // :725
+        if (done < max_runs && any && (int)inflight.size() < n_slots) {
+            PipeRound R;
+            R.T = next_round(batch, max_err, done, max_runs, parts);                    // trials of this round, all devices of all ranks together
+            R.base = (uint64_t)done; R.slot = (int)(round_index % n_slots);
+            R.pend.assign(n_L, 0); R.fresh.assign(n_L, 1);
+            inflight.push_back(R);
+            done += R.T; ++round_index;
+            ++h->last_rounds;
+            h->last_round_max_per_device = std::max(h->last_round_max_per_device, (R.T - job->part0 + parts - 1) / parts);
+        }
+        if (inflight.empty()) break;
+        job->stages.clear();
+        for (int li = 0; li < n_L; ++li) {
+            int limit = n_e;
+            for (PipeRound &R : inflight) {
+                const int start = R.pend[li];
+                int found = -1;
+                for (int ie = start; ie < limit; ++ie)
+                    if (err[li * n_e + ie] <= (uint64_t)max_err) { found = ie; break; }
+                if (found >= 0) {
+                    job->stages.push_back(McStage{li, found, R.slot, R.T, R.base, R.fresh[li] != 0});
+                    R.fresh[li] = 0;
+                    run[li * n_e + found] += (uint64_t)R.T;                            // :728
+                    R.pend[li] = found + 1;
+                } else R.pend[li] = limit;
+                limit = start;
+            }
+        }
+        while (!inflight.empty()) {
+            bool fin = true;
+            for (int li = 0; li < n_L; ++li) fin &= (inflight.front().pend[li] >= n_e);
+            if (!fin) break;
+            inflight.erase(inflight.begin());
+        }
+        if (job->stages.empty()) continue;
         std::fill(job->rcs.begin(), job->rcs.end(), POLAR_OK);
         for (auto &s_ : job->msgs) s_.clear();
         job->n_failed = 0; job->n_failed_coll = 0;
-        const auto t_round = std::chrono::steady_clock::now();
+        const auto t_step = std::chrono::steady_clock::now();
         mc->run_all(worker, h->knobs.multi_timeout_s, h->knobs.multi_grace_s);
-        h->round_us.push_back((long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_round).count());
         if (mc->timed_out) {
             rc_all = POLAR_E_DEVICE;
             err_msg = "a multi-device round exceeded the watchdog (" + std::to_string(h->knobs.multi_timeout_s) + " s): communicators aborted" +
@@ -1983,15 +2109,13 @@ int bler_impl(polar_code_t *h, int constellation, const int *devices, int n_dev,
             for (int d = 0; d < n_dev; ++d)
                 if (job->rcs[d] && (pass == 1 || job->msgs[d].compare(0, 13, "round aborted") != 0)) { rc_all = job->rcs[d]; err_msg = "device " + std::to_string(devs[d]) + ": " + job->msgs[d]; break; }
         if (rc_all) break;
-        for (int i = 0; i < P; ++i) {
-            if (!en[i]) continue;
-            for (int d = 0; d < (rccl ? 1 : n_dev); ++d) { err[i] += job->host_ctr[d][2 * i]; bit[i] += job->host_ctr[d][2 * i + 1]; }
-            run[i] += (uint64_t)T;
-        }
-        done += T;
-        ++job->round_no;
-        ++h->last_rounds;
-        h->last_round_max_per_device = std::max(h->last_round_max_per_device, job->Td[0]);
+        std::fill(tot.begin(), tot.end(), 0ull);
+        for (int d = 0; d < (rccl ? 1 : n_dev); ++d)
+            for (int i = 0; i < 2 * P; ++i) tot[i] += job->host_ctr[d][i];
+        if (reduce && reduce(reduce_user, (uint64_t *)tot.data(), 2 * P) != 0) { rc_all = POLAR_E_DEVICE; err_msg = "the counter reduction over the processes failed"; break; }
+        for (int i = 0; i < P; ++i) { err[i] += tot[2 * i]; bit[i] += tot[2 * i + 1]; }
+        h->round_us.push_back((long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_step).count());
+        ++job->step_no;
     }
     // a failed round leaves the communicators in an unknown state: abort and rebuild them next time
     if (rc_all) multi_release(h, true);
@@ -2022,6 +2146,17 @@ int polar_get_bler_quick_ber(polar_code_t *h, const double *ebno, int n_e, const
     int dev = h->device;
     if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return fail(POLAR_E_DEVICE, "no HIP device available; this library has no CPU decode path");
     return bler_impl(h, 0, &dev, 1, ebno, n_e, Ls, n_L, max_runs, max_err, seed, batch, bler_out, ber_out, nullptr, nullptr, nullptr);
+}
+int polar_get_bler_quick_rank(polar_code_t *h, int constellation, int rank, int world, polar_reduce_fn reduce, void *user,
+                              const double *axis, int n_e, const uint8_t *Ls, int n_L, long max_runs, long max_err, uint64_t seed,
+                              long batch, double *bler_out, double *ber_out, uint64_t *err_out, uint64_t *run_out, long *rounds_out) {
+    if (!h) return fail(POLAR_E_ARG, "NULL argument");
+    int dev = h->device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return fail(POLAR_E_DEVICE, "no HIP device available; this library has no CPU decode path");
+    const int rc = bler_impl(h, constellation, &dev, 1, axis, n_e, Ls, n_L, max_runs, max_err, seed, batch, bler_out, ber_out, err_out, run_out, nullptr,
+                             rank, world, reduce, user);
+    if (!rc && rounds_out) *rounds_out = h->last_rounds;
+    return rc;
 }
 int polar_debug_comm_inits(void) { return g_comm_inits.load(); }
 int polar_get_bler_quick_multi(polar_code_t *h, const int *devices, int n_dev, const double *ebno, int n_e,

@@ -80,6 +80,32 @@ def get_bler_quick_sharded(engine, ebno_vec, list_size_vec, max_runs=1000, max_e
     return bler, err, run
 
 
+def get_bler_quick_ranks(code, ebno_vec, list_size_vec, max_runs=1000, max_err=100, seed=1, global_batch=None, device=None,
+                         stats=None, constellation=None):
+    """The same sweep through the library's own driver (polar_get_bler_quick_rank): one process per GPU, this rank's device
+    simulates the trials rank, rank + world, ... of every round, the rounds are PIPELINED on the device (a step decodes point 1
+    of the newest round together with the later points of the rounds before it — polar_host.cpp mc_step_launch) and the
+    counters are summed by one all-reduce per step. Same counters as get_bler_quick_sharded and as one GPU alone.
+    Returns (bler, err, run)."""
+    rank, world = _world()
+
+    def reduce(a):
+        if world > 1:
+            t = torch.from_numpy(a.astype(np.int64))
+            if device is not None:
+                t = t.to(device)
+            dist.all_reduce(t)
+            a[:] = t.cpu().numpy().astype(np.uint64)
+    bler, _, c = code.get_bler_quick_rank(ebno_vec, list_size_vec, rank, world, reduce, max_runs=max_runs, max_err=max_err, seed=seed,
+                                          batch=global_batch or 0, constellation=constellation)
+    if stats is not None:
+        stats["rounds"] = c["rounds"]
+        stats["steps"] = c["steps"]
+        for k in ("min", "median", "max", "first"):
+            stats["step_ms_" + k] = code.debug_get("round_us_" + k) / 1e3
+    return bler, c["err"], c["run"]
+
+
 def mc_construction_sharded(counter, num_layers, design_snr_db, num_runs, constellation, seed=1, device=None):
     """Monte-Carlo code construction (PolarCode.m:143-196) sharded over GPUs: runs 0..num_runs-1 are
     split into `world` contiguous ranges, rank r counts its range with

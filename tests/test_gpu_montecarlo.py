@@ -309,6 +309,62 @@ def test_python_sharded_driver_and_strided_engine_on_the_gpu(built_lib, oracle_b
     assert np.array_equal(e_sum, e_all) and np.array_equal(r_sum, r_all)
 
 
+def test_pipelined_rounds_equal_the_round_after_round_loop(built_lib, oracle_built):
+    """The native driver pipelines the rounds on the device (a step decodes point 1 of the newest round together with the later
+    points of the rounds before: polar_host.cpp mc_step_launch); the step-wise engine (polar_mc_batch, driven round after
+    round by montecarlo.get_bler_quick_sharded) does not. Same counters, to the last one: with the early stop biting at different
+    rounds for different points and list sizes, with points that are disabled from the start (max_err = 0 after the first
+    round), with fixed and geometric rounds — and equal to the CPU restatement's step-wise engine."""
+    from polar_amd.montecarlo import get_bler_quick_sharded
+    o, g = _pair(8, 128, 8)
+    ebno, Ls = [0.0, 1.0, 2.0, 3.0, 4.0], [1, 2, 8]
+    for max_err, batch, max_runs in ((20, 200, 3000), (5, 64, 2000), (0, 100, 700), (40, 0, 5000), (10**6, 333, 2000)):
+        b1, c1 = g.get_bler_quick(ebno, Ls, max_runs=max_runs, max_err=max_err, seed=21, batch=batch, return_counters=True)
+        b2, e2, r2 = get_bler_quick_sharded(g.mc_batch, ebno, Ls, max_runs=max_runs, max_err=max_err, seed=21, global_batch=batch)
+        assert np.array_equal(c1["err"], e2) and np.array_equal(c1["run"], r2), (max_err, batch)
+        b3, e3, r3 = get_bler_quick_sharded(o.mc_batch, ebno, Ls, max_runs=max_runs, max_err=max_err, seed=21, global_batch=batch)
+        assert np.array_equal(c1["err"], e3) and np.array_equal(c1["run"], r3), (max_err, batch)
+
+
+def test_rank_driver_three_processes_stand_ins_equal_one_device(built_lib):
+    """polar_get_bler_quick_rank (what polar_amd/montecarlo.py's get_bler_quick_ranks and `bench.py --gpus N` call): three
+    "ranks" — three handles on the one GPU, one thread each, a reduce callback that sums over the three through a barrier —
+    return, each of them, the counters of one device alone; early stop included."""
+    import threading
+    o, g = _pair(8, 128, 8)
+    ebno, Ls = [0.5, 1.5, 2.5], [1, 4]
+    kw = dict(max_runs=2400, max_err=30, seed=9, batch=300)
+    want, cw = g.get_bler_quick(ebno, Ls, return_counters=True, **kw)
+    world = 3
+    codes = [g] + [_pair(8, 128, 8)[1] for _ in range(world - 1)]
+    bar = threading.Barrier(world)
+    acc = {}
+    lock = threading.Lock()
+    res = [None] * world
+
+    def reduce_for(rank):
+        def reduce(a):
+            k = bar.wait()                               # (everybody has arrived: the accumulator of the previous step is free)
+            with lock:
+                acc.setdefault("sum", np.zeros_like(a))
+                acc["sum"] += a
+            bar.wait()
+            a[:] = acc["sum"]
+            if bar.wait() == 0:
+                acc.pop("sum")
+            bar.wait()
+        return reduce
+
+    def run(rank):
+        res[rank] = codes[rank].get_bler_quick_rank(ebno, Ls, rank, world, reduce_for(rank), **kw)
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=120) for t in th]
+    for r in range(world):
+        assert res[r] is not None
+        assert np.array_equal(res[r][2]["err"], cw["err"]) and np.array_equal(res[r][2]["run"], cw["run"]) and np.array_equal(res[r][0], want)
+
+
 def test_handle_keeps_callers_device_and_rejects_bad_devices(built_lib):
     import torch
     import polar_amd
