@@ -277,6 +277,7 @@ def main():
         res["other_configs"] = other_configs(args, dev)
         res["one_codeword_per_call"] = latency_record(args, code)
         res["host_batch"] = host_batch_record(args, dev)
+        res["p1_paths"] = p1_record(args, code)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -775,6 +776,41 @@ def host_batch_record(args, dev):
     pcie = pcie_rates(dev)
     return {"abi": "polar_decode_scl_llr_batch / polar_decode_scl_llr_batch_f32 (host pointers: staging + H2D + decode + D2H inside the call)",
             "pcie": pcie, "configs": [host_batch_config(c, 65536, dev, pcie) for c in HOST_BATCH_CONFIGS]}
+
+
+def p1_record(args, code):
+    """The probability-domain members of the class surface (PolarCode::decode_scl_p1, PolarCode.cpp:110-128; PolarM decode_sc_p1,
+    PolarCode.m:290-295) — no driver of the reference calls them — through their host-pointer entry points: codewords/s of one call
+    of 8192 codewords of the benchmark code (two / one input arrays of doubles, staging included), next to decode_scl_llr through
+    ITS host entry point at the same batch, and the first 8 codewords checked against the CPU restatement."""
+    import oracle_lib
+    o = oracle_lib.Oracle(args.n, args.K, 0.32, args.crc, srand=1)
+    o.set_crc_matrix(code.crc_matrix)
+    B = 8192
+    d = torch.empty((B, code.N), dtype=torch.float64, device="cuda")
+    code.synth_llr_dev(args.seed, 0, B, code.snr_sqrt_linear(args.ebno), d.data_ptr())
+    llr = d.cpu().numpy()
+    del d
+    p1 = 1.0 / (1.0 + np.exp(llr))
+    p0 = 1.0 - p1
+    rows = []
+
+    def timed(fn):
+        fn()
+        ts = []
+        for _ in range(3):
+            t = time.perf_counter(); r = fn(); ts.append(time.perf_counter() - t)
+        return min(ts), r
+    for name, fn, ref in (("decode_scl_p1 L=4", lambda: code.decode_scl_p1(p1, p0, 4), lambda: o.decode_scl_p1(p1[:8], p0[:8], 4)),
+                          ("decode_scl_p1 L=32", lambda: code.decode_scl_p1(p1, p0, 32), lambda: o.decode_scl_p1(p1[:8], p0[:8], 32)),
+                          ("decode_sc_p1", lambda: code.decode_sc_p1(p1), lambda: o.decode_sc_p1(p1[:8])),
+                          ("decode_scl_llr L=4 (for scale)", lambda: code.decode_scl_llr(llr, 4), None),
+                          ("decode_scl_llr L=32 (for scale)", lambda: code.decode_scl_llr(llr, 32), None),
+                          ("decode_scl_llr L=1 (for scale)", lambda: code.decode_scl_llr(llr, 1), None)):
+        dt, got = timed(fn)
+        rows.append({"call": name, "batch": B, "ms": dt * 1e3, "value": B / dt, "unit": "codewords/s",
+                     "first_8_equal_cpu_restatement": (bool((np.asarray(got[:8]) == np.asarray(ref())).all()) if ref else None)})
+    return {"abi": "polar_decode_scl_p1_batch / polar_decode_sc_p1_batch (host pointers)", "rows": rows}
 
 
 def latency_record(args, code):

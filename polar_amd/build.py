@@ -25,6 +25,10 @@ SOURCES = [("polar_kernels.hip", ["POLAR_ED_TU=0"], "", []), ("polar_kernels.hip
            ("polar_kernels.hip", ["POLAR_ED_TU=2"], ".ed32", FLAGS_LIST32),
            ("polar_kernels_sc.hip", [], "", []), ("polar_kernels_p1.hip", [], "", []), ("polar_channel.hip", [], "", []),
            ("polar_construct.hip", [], "", []), ("polar_host.cpp", [], "", [])]
+# what POLAR_DEFS may name: instrumentation (measures, does not decode), trimmed development builds (fewer instantiations),
+# and the few A/B switches still open (same bits either way)
+KNOWN_DEFS = {"POLAR_MARGIN", "POLAR_SLOTHIST", "SCLAT_PROF", "POLAR_DEV_GS32", "POLAR_DEV_ONE", "POLAR_NO_FIXED_N",
+              "POLAR_NO_GUARD_INT", "POLAR_NO_COLD_HINTS", "OCC", "ED_NR"}
 ARCH = os.environ.get("POLAR_ARCH", "gfx950")      # (A/B: e.g. gfx950:xnack-)
 _flags_ok = {}
 
@@ -130,6 +134,19 @@ def build(force=False, verbose=False, profile=False, bless=False):
     if os.environ.get("POLAR_BUILD_TAG"):          # A/B experiments: separate objects and library
         tag = "." + os.environ["POLAR_BUILD_TAG"]
         lib_out = os.path.join(HERE, "libpolar_amd_%s.so" % os.environ["POLAR_BUILD_TAG"])
+    # Extra -D macros (POLAR_DEFS) select instrumented or trimmed builds — some of them measure instead of decoding (POLAR_MARGIN
+    # overwrites decoded bits with its statistics). They never get the product's library name: a tag is required, every name must be
+    # one this tree knows (a typo would otherwise build an ordinary library under an experiment's name, or the reverse), and
+    # POLAR_DEV_BUILD is defined for them (csrc/polar_device.h stops an instrumented translation unit that lacks it).
+    extra_defs = os.environ.get("POLAR_DEFS", "").split()
+    dev_build = profile or bool(extra_defs)
+    if extra_defs:
+        unknown = [d for d in extra_defs if d.split("=")[0] not in KNOWN_DEFS]
+        if unknown:
+            raise SystemExit("polar_amd.build: POLAR_DEFS names unknown macro(s) %s (known: %s)" % (unknown, sorted(KNOWN_DEFS)))
+        if not os.environ.get("POLAR_BUILD_TAG"):
+            raise SystemExit("polar_amd.build: POLAR_DEFS=%r without POLAR_BUILD_TAG: development builds never take the product "
+                             "library's name (libpolar_amd.so)" % os.environ["POLAR_DEFS"])
     headers = [os.path.join(INC, f) for f in os.listdir(INC)] + \
               [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     objs = []
@@ -143,7 +160,7 @@ def build(force=False, verbose=False, profile=False, bless=False):
                "-c", src, "-o", obj]
         if profile:
             cmd.insert(1, "-DPOLAR_PROFILE")
-        for d in defs + os.environ.get("POLAR_DEFS", "").split():
+        for d in defs + extra_defs + (["POLAR_DEV_BUILD"] if dev_build else []):
             cmd.insert(1, "-D" + d)
         cmd[1:1] = (_probe_flags(xflags) if xflags else []) + os.environ.get("POLAR_HIPCC_FLAGS", "").split()    # (+ A/B experiments with compiler options)
         fp = _fingerprint(cmd, [src] + _deps(obj, headers))

@@ -1,5 +1,12 @@
 // polar_device.h — device-side helpers shared by the decode kernels (gfx950).
 #pragma once
+// Instrumented builds (per-phase cycle counters, margin / slot histograms, the list-size-1 latency profile) write their counters
+// where a product build writes decoded bits or scratch: they measure, they do not decode. polar_amd/build.py gives them a library
+// name of their own (POLAR_BUILD_TAG or --profile) and defines POLAR_DEV_BUILD; anything else that sets one of these macros — a
+// stray POLAR_DEFS — stops here instead of shipping a decoder that is silently not bit-exact.
+#if (defined(POLAR_PROFILE) || defined(POLAR_MARGIN) || defined(POLAR_SLOTHIST) || defined(SCLAT_PROF)) && !defined(POLAR_DEV_BUILD)
+#error "measurement macro without POLAR_DEV_BUILD: build through polar_amd/build.py with POLAR_BUILD_TAG (or --profile)"
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -87,9 +87,6 @@ constexpr double ED_C40_LO = 4.248354255291589e-18 * (1.0 - 1e-10);
 // num / den for normal operands well inside the exponent range: v_rcp_f64 seed, Newton steps on the
 // reciprocal, one correction of the quotient (which squares the remaining error: <= 1 ulp)
 __device__ __forceinline__ double ed_div(double num, double den) {
-#ifdef POLAR_EXPERIMENT_FAST_DIV   // (measurement-only build: how much of the kernel time is the division's refinement)
-    return num * __builtin_amdgcn_rcp(den);
-#endif
     double r = __builtin_amdgcn_rcp(den);
     double e = __builtin_fma(-den, r, 1.0);
     r = __builtin_fma(r, e, r);
@@ -102,23 +99,14 @@ __device__ __forceinline__ double ed_div(double num, double den) {
     return __builtin_fma(e2, r, q);
 }
 __device__ __forceinline__ double ed_with_sign(double r, int signword) {     // r >= 0
-#ifndef POLAR_NO_SIGN_ASM   // one v_and_or_b32 (the compiler often emits v_and + v_or with a literal)
     int hi; asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(signword), "s"(0x80000000u), "v"(__double2hiint(r)));
     return __hiloint2double(hi, __double2loint(r));
-#else
-    return __hiloint2double(__double2hiint(r) | (signword & (int)0x80000000), __double2loint(r));
-#endif
 }
 // max / min of the MAGNITUDES as single instructions with |.| source modifiers. Written through the builtins the compiler puts a
 // canonicalising v_max_f64 x, x in front of each operand (IEEE mode: maxnum must quiet signalling NaNs) — two more VALU
 // instructions per pair, on values that are never NaN here (finite stored forms; non-finite channel values are flagged before).
-#ifndef POLAR_NO_ABSMAX_ASM
 __device__ __forceinline__ double ed_absmax(double a, double b) { double r; asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ double ed_absmin(double a, double b) { double r; asm("v_min_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
-#else
-__device__ __forceinline__ double ed_absmax(double a, double b) { return __builtin_fmax(fabs(a), fabs(b)); }
-__device__ __forceinline__ double ed_absmin(double a, double b) { return __builtin_fmin(fabs(a), fabs(b)); }
-#endif
 // f-node. `guard` collects (as a wave mask) the lanes whose |x| < 40 decision is too close to call.
 __device__ __forceinline__ double f_node_e(double a, double b, u64 &guard) {
     const double fa = fabs(a), fb = fabs(b);

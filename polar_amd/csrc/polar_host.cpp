@@ -1504,9 +1504,12 @@ static int mc_step_launch(polar_code_t *h, int constellation, uint64_t seed, con
             rows += sl.cnt;
         }
         if (rows == 0) continue;
-        if ((rc = h->d_in.ensure((size_t)rows * N))) return rc;
-        if ((rc = h->d_out.ensure((size_t)rows * K))) return rc;
-        if ((rc = h->d_bytes_a.ensure((size_t)rows * K))) return rc;      // sent info
+        // (a quarter of headroom when the buffers grow: the first steps of a call carry one round, the later ones the survivors of
+        // the rounds before as well — a 4-GiB reallocation in the middle of a sweep is a second lost)
+        const size_t cap_rows = (size_t)rows * N <= h->d_in.cap ? (size_t)rows : (size_t)rows + (size_t)rows / 4;
+        if ((rc = h->d_in.ensure(cap_rows * N))) return rc;
+        if ((rc = h->d_out.ensure(cap_rows * K))) return rc;
+        if ((rc = h->d_bytes_a.ensure(cap_rows * K))) return rc;      // sent info
         long off = 0;
         for (const McStage &s : stages) {
             if (s.li != li) continue;

@@ -100,7 +100,6 @@ __device__ __forceinline__ double f_node(double a, double b, const Tabs &tb) {
     // also the leading term of the exact expression below
     const int sx = (__double2hiint(a) ^ __double2hiint(b)) & (int)0x80000000;
     const double ms = __hiloint2double(__double2hiint(mn) | sx, __double2loint(mn));
-#ifndef POLAR_EXPERIMENT_NO_EXACT_F   // (measurement-only build: how much VALU work is NOT the exact f-node)
     if (40 > mx) {
         // |f| <= min(|a|,|b|): when that is within a few orders of the rounding noise (1e-16) the
         // reference's result IS its rounding noise (e.g. exactly 0 once e^a, e^b round to 1), so the
@@ -108,7 +107,6 @@ __device__ __forceinline__ double f_node(double a, double b, const Tabs &tb) {
         if (POLAR_UNLIKELY2(mn < 9.5367431640625e-07)) return f_literal(a, b);
         return ms + h_diff(fabs(a + b), fabs(a - b), tb);
     }
-#endif
     return (mn == 0.0) ? 0.0 : ms;     // min-sum branch
 }
 // Two f-nodes at once: same results as f_node() twice, but ONE wave-uniform branch around the two exact
@@ -117,9 +115,6 @@ __device__ __forceinline__ double f_node(double a, double b, const Tabs &tb) {
 // the unrolled layer loops it was measured slower (register pressure: -1.4 % fused loop, -25 % LDS visits). Lanes that do not need the exact value compute it on whatever they
 // hold (finite garbage at worst: the table index is masked) and discard it.
 __device__ __forceinline__ void f_node2(double a0, double b0, double a1, double b1, const Tabs &tb, double &r0, double &r1) {
-#ifdef POLAR_EXPERIMENT_NO_EXACT_F
-    r0 = f_node(a0, b0, tb); r1 = f_node(a1, b1, tb);
-#else
     const double fa0 = fabs(a0), fb0 = fabs(b0), fa1 = fabs(a1), fb1 = fabs(b1);
     const double mx0 = __builtin_fmax(fa0, fb0), mn0 = __builtin_fmin(fa0, fb0);
     const double mx1 = __builtin_fmax(fa1, fb1), mn1 = __builtin_fmin(fa1, fb1);
@@ -141,7 +136,6 @@ __device__ __forceinline__ void f_node2(double a0, double b0, double a1, double 
             if (t1) r1 = f_literal(a1, b1);
         }
     }
-#endif
 }
 // g-node: PolarCode.cpp:449-450  (1 - 2u)*a + b
 __device__ __forceinline__ double g_node(double a, double b, unsigned u) {
@@ -186,22 +180,14 @@ __device__ __forceinline__ void leaf_terms(double leaf, bool active, u64 actw, c
         const bool isl = m > 1.0;
         neg = (__double2hiint(leaf) < 0) && m != 1.0;
         al = m;
-#ifndef POLAR_NO_ACTW
         const u64 m_e = actw & __builtin_amdgcn_fcmp(m, 1.0, 13);           // ULE: active lanes holding an E-form value
         if (POLAR_LIKELY2(m_e != 0)) {
-#else
-        if (POLAR_LIKELY2(wave_any(active && !isl))) {
-#endif
             const double l = -ed_log(__builtin_fmin(__builtin_fmax(m, ED_EMIN), 1.0), tb);
             if (!isl) al = l;
         }
         const double onep = 1.0 + m;                 // == 1 exactly from E <= 2^-53 on, as the reference's 1 + e^-|x|
         sneg = 0.0;
-#ifndef POLAR_NO_ACTW
         if (POLAR_LIKELY2((m_e & __builtin_amdgcn_fcmp(onep, 1.0, 14)) != 0)) {      // UNE
-#else
-        if (POLAR_LIKELY2(wave_any(active && !isl && onep != 1.0))) {
-#endif
             const double h = log_1p2(__builtin_fmin(onep, 2.0), tb);
             if (!isl) sneg = h;
         }
@@ -233,9 +219,7 @@ __device__ __forceinline__ const double *ch_row(const PolarDecodeParams &p, size
 #ifndef POLAR_SKIP_L1
 #define POLAR_SKIP_L1 1      // the layer of size 1 is never stored (+0.45 %)
 #endif
-#ifndef POLAR_NO_SADDR
 #define POLAR_SADDR 1        // HBM rows of the four-layer visits addressed as SGPR base + 32-bit lane offset (+0.4 %)
-#endif
 #ifndef OCC
 #define OCC 4
 #endif
@@ -293,15 +277,9 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     if (WPB > 1) __syncthreads();
     const Tabs tb = {tabs, tabs + 64, tabs + 64 + 129};
     u64 guard = 0;                                  // (ED) wave mask of lanes with an undecidable |x| < 40 test
-#ifndef POLAR_NO_GMIN
     double gacc = __builtin_inf();                  // (ED) per lane: smallest distance of a node's smaller E to the |x| < 40 threshold
-#endif
     auto FN = [&](double a, double b) -> double {
-#ifndef POLAR_NO_GMIN
         if constexpr (ED) return f_node_e_acc(a, b, gacc); else return f_node(a, b, tb);
-#else
-        if constexpr (ED) return f_node_e(a, b, guard); else return f_node(a, b, tb);
-#endif
     };
     // g-node of element with partial-sum bit `bi` of the word `cw_` (u = (cw_ >> bi) & 1)
     auto GN = [&](double a, double b, uint32_t cw_, int bi) -> double {
@@ -342,19 +320,13 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         const bool valid = (cwi < Bv);
         const long cw = (p.cw_list && valid) ? (long)p.cw_list[cwi] : cwi;   // codeword (row of llr / out)
         guard = 0;
-#ifndef POLAR_NO_GMIN
         gacc = __builtin_inf();
-#endif
         auto cw_of_lane = [&](int ln) -> size_t {
             const long i = g0 + (LAT ? 0 : ln / GS);
             return p.cw_list ? (size_t)p.cw_list[i < Bv ? i : Bv - 1] : (size_t)i;     // (lanes past the end of the work list: any valid row)
         };
         auto FN2 = [&](double a0_, double b0_, double a1_, double b1_, double &r0_, double &r1_) {
-#ifndef POLAR_NO_GMIN
             if constexpr (ED) { r0_ = f_node_e_acc(a0_, b0_, gacc); r1_ = f_node_e_acc(a1_, b1_, gacc); }
-#else
-            if constexpr (ED) { r0_ = f_node_e(a0_, b0_, guard); r1_ = f_node_e(a1_, b1_, guard); }
-#endif
             else f_node2(a0_, b0_, a1_, b1_, tb, r0_, r1_);
         };
 
@@ -639,15 +611,11 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
 #endif
                 if (!PIPE && S >= 8 && 2 * S > SL && lam + 1 <= lam_stop && ((phi >> (sh - 1)) & 1) == 0) {   // (lam+1 is an f-visit)
                     const int H = S / 2;
-#ifdef POLAR_NO_FUSED4
-                    const bool deep = false;
-#else
 #ifdef POLAR_SADDR
                     // (not from the prefix buffer, whose rows are per codeword: once per codeword, left to the two-layer body)
                     const bool deep = (lam + 3 <= lam_stop) && (phi & (S - 1)) == 0 && !(lam > 1 && p.prefix_q > 0 && 2 * S >= p.prefix_q && phi < 2 * S);
 #else
                     const bool deep = (lam + 3 <= lam_stop) && (phi & (S - 1)) == 0;        // four layers at once (else two)
-#endif
 #endif
                     if (active) {
                         LANE_CTX
@@ -811,11 +779,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                         if (deep) {
                             const int Q = S / 4, E8 = S / 8;
                             // (also streaming the layer of size 32, so that only the layer of size 16 competes for the L2: -0.5 %)
-#if !defined(POLAR_NO_NT)
 #define POLAR_NTM(x) std::integral_constant<int, (x)>{}
-#else
-#define POLAR_NTM(x) std::integral_constant<int, 0>{}
-#endif
                             typedef std::integral_constant<bool, false> TS0;
 #ifdef POLAR_SADDR
 #define POLAR_GOUT(T) (g_llr + (size_t)((T) - 2 * SL) * 64)
@@ -1136,13 +1100,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                     unsigned gh = active ? (unsigned)__double2hiint(gm) : 0u;
                     unsigned bh = active ? (unsigned)__double2hiint(bl) : 0xFFFFFFFFu;
                     group_max_min_u32<GS>(gh, bh);
-#ifndef POLAR_NO_ACTW
                     const u64 m_ok = __builtin_amdgcn_sicmp(nact, 0, 32) | (__builtin_amdgcn_sicmp(nact, L, 32) & __builtin_amdgcn_uicmp(gh, bh, 36));   // EQ, EQ, ULT
                     fast = ((m_ok | ~group_result_rows<GS>()) == ~0ull);
-#else
-                    const bool ok = (nact == 0) || (nact == L && gh < bh);
-                    fast = ((__ballot(ok) | ~group_result_rows<GS>()) == ~0ull);
-#endif
                 }
                 double gmax = 0.0;
                 if (!fast) {
@@ -1506,9 +1465,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         }
         if constexpr (ED) {
             // codewords with an undecidable |x| < 40 test go to the LLR-domain kernel (host: fallback pass)
-#ifndef POLAR_NO_GMIN
             guard |= __ballot(gacc <= ED_GACC_FLAG);
-#endif
             if constexpr (LAT) { if (valid && lane == 0) p.flags[cw] = (guard != 0) ? 1 : 0; }      // (no conversion pass has cleared it)
             else if (valid && lig == 0 && ((guard >> gbase) & gmask) != 0) p.flags[cw] = 1;
         }

@@ -200,3 +200,18 @@ def test_environment_knobs_are_read_once_and_validated(built_lib, monkeypatch):
     body = body[:body.index("\n}\n")]
     assert src.count("getenv(") == body.count("getenv(") > 0      # every getenv of the library sits in read_env_knobs
     assert "FAIL" not in body and "SHARE" not in body              # (no environment form of the test hooks)
+
+
+def test_build_refuses_development_macros_under_the_product_name():
+    """POLAR_DEFS selects instrumented builds that measure instead of decoding: polar_amd/build.py accepts only names it knows,
+    and only together with POLAR_BUILD_TAG (a library name of its own) — a typo or a stray variable cannot ship a decoder that is
+    silently not bit-exact as libpolar_amd.so."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("POLAR_BUILD_TAG", None)
+    for defs, msg in (("POLAR_MARGINN", "unknown macro"), ("POLAR_MARGIN", "without POLAR_BUILD_TAG"), ("POLAR_EXPERIMENT_FAST_DIV", "unknown macro")):
+        r = subprocess.run([sys.executable, "-m", "polar_amd.build"], cwd=ROOT, env=dict(env, POLAR_DEFS=defs), capture_output=True, text=True)
+        assert r.returncode != 0 and msg in (r.stderr + r.stdout), (defs, r.stderr[-300:])
+    src = "".join(open(os.path.join(ROOT, "polar_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "polar_amd", "csrc")))
+    assert "POLAR_EXPERIMENT" not in src
