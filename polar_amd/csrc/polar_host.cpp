@@ -913,7 +913,7 @@ static int decode_impl(polar_code_t *h, const void *d_llr, int llr_f32, long B, 
         const int blocks = (int)std::min<long>(B, lat_resident);
         if (lat_ed) {
             // (sized for the largest batch this path ever takes — a few hundred entries — so that the first call reserves it)
-            const size_t cap = (size_t)std::max<long>(B, h->knobs.lat_max_b > 0 ? h->knobs.lat_max_b : lat_resident);
+            const size_t cap = (size_t)std::max<long>(B, lat_resident);
             if ((rc = h->d_flags.ensure(cap))) return rc;
             if ((rc = h->d_list.ensure(cap))) return rc;
             if ((rc = h->d_count.ensure(1))) return rc;
