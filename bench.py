@@ -803,7 +803,7 @@ def p1_record(args, code):
         return min(ts), r
     for name, fn, ref in (("decode_scl_p1 L=4", lambda: code.decode_scl_p1(p1, p0, 4), lambda: o.decode_scl_p1(p1[:8], p0[:8], 4)),
                           ("decode_scl_p1 L=32", lambda: code.decode_scl_p1(p1, p0, 32), lambda: o.decode_scl_p1(p1[:8], p0[:8], 32)),
-                          ("decode_sc_p1", lambda: code.decode_sc_p1(p1), lambda: o.decode_sc_p1(p1[:8])),
+                          ("decode_sc_p1", lambda: code.decode_sc_p1(p1), lambda: np.stack([o.decode_sc_p1(p1[i]) for i in range(8)])),
                           ("decode_scl_llr L=4 (for scale)", lambda: code.decode_scl_llr(llr, 4), None),
                           ("decode_scl_llr L=32 (for scale)", lambda: code.decode_scl_llr(llr, 32), None),
                           ("decode_scl_llr L=1 (for scale)", lambda: code.decode_scl_llr(llr, 1), None)):
