@@ -1259,7 +1259,10 @@ int polar_decode_scl_p1_batch(polar_code_t *h, const double *p1, const double *p
     const int N = h->N;
     const int gs = pow2ceil(L), G = 64 / gs;
     long groups = (B + G - 1) / G;
-    int grid = (int)std::min<long>(groups, (long)h->num_cu * 4);
+    // (one wave per block, the whole state in a per-wave scratch of 2 N rows: 16 waves per CU hide its latency — round 4 launched 4 —
+    // as long as the scratch of all of them stays below 24 GiB)
+    int grid = (int)std::min<long>(groups, (long)h->num_cu * 16);
+    grid = (int)std::max<long>(1, std::min<long>(grid, (long)((24ull << 30) / ((size_t)N * 64 * 2 * sizeof(double)))));
     const size_t cwords = (N >= 128) ? (size_t)(N / 32 - 2) : 0;
     if ((rc = h->d_in.ensure((size_t)B * N * 2))) return rc;
     if ((rc = h->d_out.ensure((size_t)B * h->K))) return rc;
@@ -1293,7 +1296,8 @@ int polar_decode_sc_p1_batch(polar_code_t *h, const double *p1, long B, double *
     int rc = ensure_device(h, dg_);
     if (rc) return rc;
     const int N = h->N;
-    int grid = (int)std::min<long>((B + 63) / 64, (long)h->num_cu * 4);
+    int grid = (int)std::min<long>((B + 63) / 64, (long)h->num_cu * 16);
+    grid = (int)std::max<long>(1, std::min<long>(grid, (long)((24ull << 30) / ((size_t)N * 64 * 4 * sizeof(double)))));
     if ((rc = h->d_in.ensure((size_t)B * N + (size_t)B * h->K))) return rc;
     if ((rc = h->d_llr_scr.ensure((size_t)grid * 4 * N * 64 + 64))) return rc;
     HIP_TRY(hipMemcpy(h->d_in.p, p1, (size_t)B * N * sizeof(double), hipMemcpyHostToDevice));
