@@ -247,7 +247,7 @@ int polar_set_tuning(polar_code_t *h, int waves_per_cu, int lds_log);
  * channels (explicit tables, rates near 1) the reference itself decides on the rounding noise of glibc's exp/log, which no
  * other arithmetic reproduces bit for bit: the handle marks such leaves at creation (BEC(1/2) capacity below 1e-3) and every
  * codeword in which one of them comes out below 1e-8 is decoded by the LLR-domain kernel whatever the mode, so automatic
- * mode is never worse there than mode 1 (DESIGN.md "Where bit-exactness ends"; tests/test_gpu_fuzz.py). With list sizes
+ * mode is never worse there than mode 1 (HISTORY.md "Where bit-exactness ends"; tests/test_gpu_fuzz.py). With list sizes
  * below 3 mode 2 falls back to the LLR-domain kernel (the exp-domain kernels exist for groups of 4 lanes and more).
  * Environment overrides (measurement and tests only) are read ONCE, when a handle is created, and validated — no entry
  * point calls getenv afterwards: POLAR_MODE=<0|1|2> replaces the handle's mode (any other value: creation fails);

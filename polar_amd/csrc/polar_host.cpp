@@ -387,7 +387,7 @@ int derive_tables(polar_code *h) {
     for (int i = 0; i < N; ++i) h->ctl[i] = (uint32_t)(h->frozen[i] ? 1u : 0u) | ((uint32_t)h->sched[i] << 1);
     // Unfrozen leaves in the worst synthetic channels (explicit tables, rates near 1, a design parameter that does not
     // describe the channel): their LLR is an f-chain over hundreds of channel values, 1e-30 and below, and what the
-    // reference decides on is the rounding noise of its own arithmetic (DESIGN.md "Where bit-exactness ends"). The
+    // reference decides on is the rounding noise of its own arithmetic (HISTORY.md "Where bit-exactness ends"). The
     // LLR-domain kernel follows that arithmetic much further down than the exp-domain one, whose stored form resolves
     // 1e-16 ABSOLUTE near 0. Classified here, once, at no cost per decode: a leaf whose capacity over a BEC(1/2) is
     // below 1e-3 (1 - z, tracked as such: z itself rounds to 1) gets bit 8 of its control word, and the exp-domain

@@ -128,7 +128,7 @@ def test_mex_gateway_compiles_syntax_only():
 
 
 def test_weak_unfrozen_leaves_are_classified_at_creation(built_lib):
-    """Host side of the round-3 parity guard (DESIGN.md "Where bit-exactness ends"): codes a construction produces for an
+    """Host side of the round-3 parity guard (HISTORY.md "Where bit-exactness ends"): codes a construction produces for an
     ordinary channel have no unfrozen leaf in the worst synthetic channels; rates near 1 / a design parameter that does not
     describe the channel do; the reference's 16-ASK BICM table has one (its bit levels are unequal: under a BEC it looks
     weak, on its own channel it is not — the device guard looks at the VALUE before it acts)."""

@@ -43,7 +43,7 @@ def test_fuzz_slice_codes_a_construction_produces(built_lib, oracle_built):
 def test_weak_unfrozen_leaves_take_the_llr_domain_kernel(built_lib, oracle_built, n, K, eps, L, ebno):
     """Codes with unfrozen leaves in the worst channels (rate near 1 / a design parameter that does not describe the
     channel): the reference's decisions there are the rounding noise of its own arithmetic, which the LLR-domain kernel
-    follows much further down than the exp-domain one (DESIGN.md "Where bit-exactness ends": 664 vs 60 differing codewords
+    follows much further down than the exp-domain one (HISTORY.md "Where bit-exactness ends": 664 vs 60 differing codewords
     of 4 096 at K = 505 of 512, L = 5). The handle classifies such leaves at creation and the exp-domain kernel hands every
     codeword in which one of them comes out below 1e-8 to the LLR-domain kernel: automatic mode must not be worse than
     the LLR-domain kernel alone."""

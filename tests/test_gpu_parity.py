@@ -479,7 +479,7 @@ def test_degenerate_rows_mixed_with_normal_ones(built_lib, oracle_built, L):
 def test_one_codeword_at_a_time_equals_the_batch(built_lib, oracle_built, L):
     """The reference's loops call the decoder one codeword at a time (PolarCode.cpp:756, PolarM/main_MC_CC_Comparison.m:96):
     B = 1 through the host-pointer ABI returns, codeword for codeword, what one batched call returns (and the oracle's bits).
-    Latency / crossover table: profiles/r03/latency_table.json, DESIGN.md §5c."""
+    Latency / crossover table: profiles/r03/latency_table.json, DESIGN.md §7."""
     o, g = _pair(11, 1024, 16)
     llr, _ = o.synth_llr(31, 0, 24, o.snr_sqrt_linear(1.5))
     batch = g.decode_scl_llr(llr, L)
