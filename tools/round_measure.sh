@@ -4,11 +4,14 @@
 # usage: tools/round_measure.sh <tag>
 T=${1:-r03}; O=gpurun_out/$T; mkdir -p $O
 sha256sum polar_amd/libpolar_amd.so > $O/lib_sha256.txt
-(timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3) > $O/gpu_tests.txt
+(timeout 1800 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3) > $O/gpu_tests.txt
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --batch 524288 --cpu-sample 0 --no-other-configs --mc-trials 0 > $O/bench_b524288.json 2>> $O/bench.err
 bash tools/profile.sh ${T} --steps 2 --warmup 1 --no-other-configs --mc-trials 0 > /dev/null 2>&1
-bash tools/profile_configs.sh config1 config2 config2_b262144 config3 config5 > $O/profile_configs.log 2>&1
+bash tools/profile_configs.sh config1 config2 config2_b262144 config3 config5 config3_b262144 config5_b262144 > $O/profile_configs.log 2>&1
+python tools/host_path.py --out $O/host_path_65536.json > $O/host_path_65536.txt 2>&1
+python tools/host_path.py --batch 262144 --out $O/host_path_262144.json > $O/host_path_262144.txt 2>&1
+(cd /tmp && export TMPDIR=/tmp && cd $OLDPWD && rocprofv3 --kernel-trace --output-format csv -d gpurun_out/host_trace_$T -- python tools/host_trace.py config3 0 > $O/host_trace_config3.log 2>&1; python tools/host_trace.py --report gpurun_out/host_trace_$T > $O/host_trace_config3.txt 2>&1)
 rm -rf gpurun_out/ic1 gpurun_out/ic2; bash tools/icache_pmc.sh 2>&1 | tail -2 > $O/icache_pmc.txt
 mkdir -p gpurun_out/st_$T; bash tools/stall_pmc.sh $T 2>&1 | tail -4 > $O/stall_pmc.txt
 python tools/bler_sweeps.py $O/bler_sweeps.json > $O/bler_sweeps.txt 2>&1
