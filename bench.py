@@ -704,7 +704,7 @@ def pcie_rates(dev, mib=256):
     return out
 
 
-def host_batch_config(name, B, dev, pcie, settings=(("default", {}),), reps=3, seed=7):
+def host_batch_config(name, B, dev, pcie, settings=(("default", {}),), reps=5, seed=7):
     """One configuration through the HOST-POINTER batch entry points (polar_decode_scl_llr_batch / _f32 — the only path a MEX or
     PolarCode.hpp caller has: PolarCode.cpp:130-148, PolarM/PolarCode.m:312-322) from PAGEABLE numpy memory: codewords/s
     including staging, H2D, decode, D2H, next to the device-resident rate of the same batch and the bound

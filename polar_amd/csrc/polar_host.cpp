@@ -1022,8 +1022,12 @@ static int hostpipe_ensure(polar_code_t *h, size_t in_slot, size_t out_slot, int
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (!hp->copy) HIP_TRY(hipStreamCreateWithPriority(&hp->copy, hipStreamNonBlocking, prio_greatest));
-    for (int l = 0; l < lanes; ++l)
-        if (!hp->lane[l]) HIP_TRY(hipStreamCreateWithPriority(&hp->lane[l], hipStreamNonBlocking, l == 1 ? prio_least : (prio_least + prio_greatest) / 2));
+    for (int l = 0; l < lanes; ++l) {
+        // lanes beyond the third (polar_debug_set "host_lanes" only) are spread over the three pools
+        static const int pool_of[HostPipe::kMaxLanes] = {0, 1, 0, 2, 1, 2, 0, 1};      // 0 normal, 1 low, 2 high
+        const int prio = pool_of[l] == 1 ? prio_least : pool_of[l] == 2 ? prio_greatest : (prio_least + prio_greatest) / 2;
+        if (!hp->lane[l]) HIP_TRY(hipStreamCreateWithPriority(&hp->lane[l], hipStreamNonBlocking, prio));
+    }
     for (int i = 0; i < R; ++i) {
         if (!hp->h2d[i]) HIP_TRY(hipEventCreateWithFlags(&hp->h2d[i], hipEventDisableTiming));
         if (!hp->done[i]) HIP_TRY(hipEventCreateWithFlags(&hp->done[i], hipEventDisableTiming));

@@ -22,6 +22,8 @@ import bench
 SWEEP = [("off (one copy in, decode, one copy out)", {"host_pipe_min_bytes": -1}),
          ("no ramp", {"host_ramp": -1}),
          ("one lane", {"host_lanes": 1}), ("two lanes", {"host_lanes": 2}), ("three lanes", {"host_lanes": 3}), ("four lanes", {"host_lanes": 4}),
+         ("five lanes", {"host_lanes": 5}), ("six lanes", {"host_lanes": 6}), ("eight lanes", {"host_lanes": 8}),
+         ("six lanes, chunk 64 MiB", {"host_lanes": 6, "host_chunk_bytes": 64 << 20}),
          ("chunk 32 MiB", {"host_chunk_bytes": 32 << 20}), ("chunk 64 MiB", {"host_chunk_bytes": 64 << 20}),
          ("chunk 128 MiB", {"host_chunk_bytes": 128 << 20}), ("chunk 256 MiB", {"host_chunk_bytes": 256 << 20}),
          ("chunk 256 MiB, 2 lanes", {"host_chunk_bytes": 256 << 20, "host_lanes": 2}),
