@@ -84,8 +84,12 @@ classdef PolarCode < handle
             u = double(polar_mex('decode_scl_p1', obj.h, double(p1(:)'), double(p0(:)'), list_size));
         end
         function u = decode_scl_llr(obj, llr, list_size)
-            % llr may be 1 x N or B x N (one codeword per row): rows are decoded as one GPU batch
-            u = double(polar_mex('decode_scl_llr', obj.h, double(llr), list_size));
+            % llr may be 1 x N, B x N (one codeword per row -> u is B x K) or N x B (one codeword per COLUMN -> u is K x B:
+            % MATLAB's column-major storage is then the library's and nothing is transposed on either side — the layout
+            % for large batches); double or single (single halves the bytes that cross the PCIe link). One GPU batch;
+            % from 32 MiB of LLRs on the library pipelines the copy and the decode.
+            if ~isa(llr, 'single'), llr = double(llr); end
+            u = double(polar_mex('decode_scl_llr', obj.h, llr, list_size));
         end
         function [bler, ber] = get_bler_quick(obj, ebno_vec, list_size_vec, max_runs, max_err, seed, devices, constellation_id)
             % [bler, ber] indexed (i_ebno, i_list) as PolarM (:781-850); PolarM constants max_err=50, max_runs=500

@@ -9,6 +9,7 @@
 
 #include "mex.h"
 #include "polar_amd.h"
+#include "polar_mex_layout.h"
 
 static void check(int rc) {
     if (rc < 0) mexErrMsgIdAndTxt("polar_amd:error", "%s", polar_last_error());
@@ -129,18 +130,32 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         plhs[0] = mxCreateNumericMatrix(1, N, mxUINT8_CLASS, mxREAL);
         check(polar_encode(h, (const uint8_t *)mxGetData(prhs[2]), (uint8_t *)mxGetData(plhs[0])));
     } else if (c == "decode_scl_llr") {
-        // B x N column-major from MATLAB -> row-major batch
-        size_t B = mxGetM(prhs[2]), cols = mxGetN(prhs[2]);
-        if (cols != (size_t)N) { if (B * cols == (size_t)N) { B = 1; } else mexErrMsgIdAndTxt("polar_amd:size", "llr must be B x N"); }
-        const double *x = mxGetPr(prhs[2]);
-        std::vector<double> llr(B * N);
-        if (B == 1) memcpy(llr.data(), x, sizeof(double) * N);
-        else for (size_t b = 0; b < B; ++b) for (int i = 0; i < N; ++i) llr[b * N + i] = x[(size_t)i * B + b];
-        std::vector<uint8_t> out(B * K);
-        check(polar_decode_scl_llr_batch(h, llr.data(), (long)B, (int)mxGetScalar(prhs[3]), out.data()));
-        plhs[0] = mxCreateNumericMatrix(B, K, mxUINT8_CLASS, mxREAL);
-        uint8_t *d = (uint8_t *)mxGetData(plhs[0]);
-        for (size_t b = 0; b < B; ++b) for (int i = 0; i < K; ++i) d[(size_t)i * B + b] = out[b * K + i];
+        // u = polar_mex('decode_scl_llr', h, llr, list_size): llr double or single; 1 x N, B x N (one codeword per row -> u is
+        // B x K) or N x B (one codeword per COLUMN -> u is K x B: MATLAB's storage is then the library's, nothing is copied on
+        // either side). Batches from 32 MiB on are pipelined inside the library (pinned staging, copy stream, decode lanes).
+        size_t B = 0;
+        const char lay = polar_mex::batch_layout(mxGetM(prhs[2]), mxGetN(prhs[2]), (size_t)N, &B);
+        if (!lay) mexErrMsgIdAndTxt("polar_amd:size", "llr must be 1 x N, B x N or N x B");
+        const bool f32 = mxGetClassID(prhs[2]) == mxSINGLE_CLASS;
+        if (!f32 && mxGetClassID(prhs[2]) != mxDOUBLE_CLASS) mexErrMsgIdAndTxt("polar_amd:type", "llr must be double or single");
+        const int L = (int)mxGetScalar(prhs[3]);
+        const void *src = mxGetData(prhs[2]);
+        std::vector<double> t64;
+        std::vector<float> t32;
+        if (lay == 'r' && B > 1) {                       // gather the rows (blocked, multi-threaded)
+            if (f32) { t32.resize(B * N); polar_mex::rows_from_colmajor((const float *)src, B, (size_t)N, t32.data()); src = t32.data(); }
+            else { t64.resize(B * N); polar_mex::rows_from_colmajor((const double *)src, B, (size_t)N, t64.data()); src = t64.data(); }
+        }
+        if (lay == 'c') {
+            plhs[0] = mxCreateNumericMatrix(K, B, mxUINT8_CLASS, mxREAL);
+            uint8_t *d = (uint8_t *)mxGetData(plhs[0]);
+            check(f32 ? polar_decode_scl_llr_batch_f32(h, (const float *)src, (long)B, L, d) : polar_decode_scl_llr_batch(h, (const double *)src, (long)B, L, d));
+        } else {
+            std::vector<uint8_t> out(B * K);
+            check(f32 ? polar_decode_scl_llr_batch_f32(h, (const float *)src, (long)B, L, out.data()) : polar_decode_scl_llr_batch(h, (const double *)src, (long)B, L, out.data()));
+            plhs[0] = mxCreateNumericMatrix(B, K, mxUINT8_CLASS, mxREAL);
+            polar_mex::colmajor_from_rows(out.data(), B, (size_t)K, (uint8_t *)mxGetData(plhs[0]));
+        }
     } else if (c == "decode_scl_p1") {
         plhs[0] = mxCreateNumericMatrix(1, K, mxUINT8_CLASS, mxREAL);
         check(polar_decode_scl_p1(h, mxGetPr(prhs[2]), mxGetPr(prhs[3]), (int)mxGetScalar(prhs[4]),

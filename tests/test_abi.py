@@ -124,7 +124,20 @@ def test_mex_gateway_compiles_syntax_only():
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(root, "tests", "mex_stub"),
-                           "-I", os.path.join(root, "include"), os.path.join(root, "polar_amd", "matlab", "polar_mex.cpp")])
+                           "-I", os.path.join(root, "include"), "-I", os.path.join(root, "polar_amd", "matlab"),
+                           os.path.join(root, "polar_amd", "matlab", "polar_mex.cpp")])
+
+
+def test_mex_gateway_layout_helpers(tmp_path):
+    """The part of the MEX gateway that CAN run without MATLAB: the column-major <-> codeword-contiguous conversions of a batch
+    (blocked, multi-threaded) and the N x B / B x N / vector layout rule, against a naive loop (tests/mex_stub/layout_test.cpp)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "layout_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", "-I", os.path.join(root, "polar_amd", "matlab"),
+                           os.path.join(root, "tests", "mex_stub", "layout_test.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
 
 
 def test_weak_unfrozen_leaves_are_classified_at_creation(built_lib):
