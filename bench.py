@@ -263,7 +263,14 @@ def main():
 
     if args.mc_trials > 0:
         del llr, sent
-        res["monte_carlo"] = monte_carlo_leg(args, code, dist, dev, rank, world, shared_gpu=shared)
+        if world == 1:        # (with peers a failure on one rank cannot be contained here: the others wait in a collective)
+            try:
+                res["monte_carlo"] = monte_carlo_leg(args, code, dist, dev, rank, world, shared_gpu=shared)
+            except Exception as ex:
+                res["monte_carlo"] = {"error": f"{type(ex).__name__}: {ex}"[:500]}
+                torch.cuda.synchronize()
+        else:
+            res["monte_carlo"] = monte_carlo_leg(args, code, dist, dev, rank, world, shared_gpu=shared)
         if not res["monte_carlo"].get("native_multi_hung"):                 # (else a thread is still inside the handle: hands off)
             llr = torch.empty((B, N), dtype=torch.float64, device=dev)      # (the CPU baseline below re-checks the batch)
             code.synth_llr_dev(args.seed, trial0, B, s, llr.data_ptr(), 0)
@@ -271,13 +278,23 @@ def main():
     if shared:
         res["shared_gpu_test"] = True
     hung = bool(res.get("monte_carlo", {}).get("native_multi_hung"))
+    def guarded(name, fn):
+        """The records beside the headline must not be able to take the result line with them: a failure in one of them is
+        recorded in its place."""
+        try:
+            res[name] = fn()
+        except Exception as ex:
+            import traceback
+            res[name] = {"error": f"{type(ex).__name__}: {ex}"[:500], "traceback_tail": traceback.format_exc()[-800:]}
+            torch.cuda.synchronize()
+
     if rank == 0 and world == 1 and args.cpu_sample != 0 and not hung:
-        res["cpu_baseline"] = cpu_baseline(args, code, llr, out)
+        guarded("cpu_baseline", lambda: cpu_baseline(args, code, llr, out))
     if rank == 0 and world == 1 and not args.no_other_configs and not hung:
-        res["other_configs"] = other_configs(args, dev)
-        res["one_codeword_per_call"] = latency_record(args, code)
-        res["host_batch"] = host_batch_record(args, dev)
-        res["p1_paths"] = p1_record(args, code)
+        guarded("other_configs", lambda: other_configs(args, dev))
+        guarded("one_codeword_per_call", lambda: latency_record(args, code))
+        guarded("host_batch", lambda: host_batch_record(args, dev))
+        guarded("p1_paths", lambda: p1_record(args, code))
     if dist:
         dist.barrier()
         dist.destroy_process_group()
