@@ -90,7 +90,12 @@ int polar_decode_scl_llr(polar_code_t *h, const double *llr /*[N]*/, int L, uint
  * PolarM/main_MC_CC_Comparison.m:96) — take latency kernels with ONE codeword per wave and the decoder state in LDS: list size 1
  * up to 2048 codewords (N <= 4096), list sizes 2 .. 8 up to one codeword per CU while the state fits 160 KiB of LDS (N = 2048: lists
  * up to 4; N = 1024: up to 8). Same bits as the batch kernels (tests/: every such test runs both). Batches of at most 64
- * codewords at list size 1 are staged in pinned, device-mapped host memory (no DMA copies). */
+ * codewords at list size 1 are staged in pinned, device-mapped host memory (no DMA copies).
+ * Large batches (from 32 MiB of LLRs) are PIPELINED inside the call: chunks are copied from the caller's (pageable) memory into
+ * pinned slots by a few host threads, moved on a copy stream and decoded on two or three decode lanes with their own scratch
+ * (the handle keeps slots, streams, lanes and threads: 0.3 - 1.3 GiB of pinned and device memory after the first such call):
+ * min(device rate, PCIe rate) minus one decode launch, whatever the batch size; device memory use is bounded by the slots,
+ * not by B. Same bits as one decode of the whole batch (tests/test_gpu_parity.py: chunk boundaries). */
 int polar_decode_scl_llr_batch(polar_code_t *h, const double *llr, long B, int L, uint8_t *out);
 /* device-resident: d_llr/d_out live in HBM; asynchronous on `stream` (hipStream_t).
  * d_pm (optional, may be NULL) receives the winning path metric per codeword. */
@@ -178,10 +183,15 @@ int polar_get_bler_quick_multi(polar_code_t *h, const int *devices, int n_dev, c
  * ber_out, the raw counters err_out / run_out [n_L*n_e] (block errors and simulated-or-counted runs per point: what the
  * estimates are made of, and what two runs are compared by), *rounds_out = rounds the call took, *used_rccl.
  * Rounds: `batch` trials over all devices, or (batch == 0) geometric up to 262144 trials PER DEVICE.
- * Failure handling: a device that fails before the round's collective keeps every device out of it; a device whose
- * collective enqueue fails makes every device abort its communicator before it synchronises; a round that exceeds the
- * watchdog (1800 s; polar_debug_set "multi_timeout_s") has its communicators aborted from the calling thread. The call then
- * returns POLAR_E_DEVICE and the next call rebuilds the communicators. */
+ * The rounds are pipelined on the device — a step decodes point 1 of the newest round together with the later points of the
+ * rounds before it, one launch per list size — with exactly the counters, early stop and run counts of the round-after-round
+ * loop; the counters are reduced once per step.
+ * Failure handling: a device that fails before the step's collective keeps every device out of it; a device whose
+ * collective enqueue fails makes every device abort its communicator before it waits; a step that exceeds the watchdog
+ * (1800 s; polar_debug_set "multi_timeout_s") is ended in three bounded stages ("multi_grace_s", 10 s each): the workers are
+ * signalled and abort their own communicators, what is left is aborted from the calling thread, and a worker that still does
+ * not answer is given up — the call returns, the handle accepts no further get_bler_quick* calls and polar_destroy frees
+ * nothing of it. Otherwise the call returns POLAR_E_DEVICE and the next call rebuilds the communicators. */
 int polar_get_bler_quick_multi_ex(polar_code_t *h, int constellation, const int *devices, int n_dev, const double *axis, int n_e,
                                   const uint8_t *L, int n_L, long max_runs, long max_err, uint64_t seed, long batch,
                                   double *bler_out, double *ber_out, uint64_t *err_out, uint64_t *run_out, long *rounds_out,
@@ -266,7 +276,12 @@ int polar_debug_weak_leaves(const polar_code_t *h);
  * may be listed several times in a device list), "fail_device" = d / "fail_collective" = d (worker d reports a failure in
  * its second round before / after the barrier that precedes the counter reduction; -1 = off), "multi_timeout_s".
  * polar_debug_get: "allocs" (hipMalloc calls of all handles' scratch so far), "comm_inits", "weak_leaves",
- * "last_rounds", "last_round_max_per_device", "worker_threads_started" (of the handle's last get_bler_quick* calls). */
+ * "last_rounds", "last_round_max_per_device", "worker_threads_started" (of the handle's last get_bler_quick* calls).
+ * "multi_grace_s", "force_workers", "stall_device" / "stall_ms" (watchdog tests), "host_pipe_min_bytes" / "host_chunk_bytes" /
+ * "host_lanes" / "host_threads" / "host_ramp" (the pipelined host-pointer path; polar_debug_get "host_chunks", "host_chunk_cw",
+ * "host_lanes", "host_threads", "host_us_*"), polar_debug_get "round_us_first|min|median|max|count" (steps of the last sweep),
+ * "multi_poisoned". Like every entry point, the hooks must not run concurrently with another call on the same handle; the knobs
+ * that shape the cached multi-device context ("no_rccl", "force_rccl", "share_device", "force_workers") drop it. */
 int polar_debug_set(polar_code_t *h, const char *key, long value);
 long polar_debug_get(const polar_code_t *h, const char *key);
 void *polar_debug_scratch_ptr(polar_code_t *h);      /* measurement builds only: where instrumented kernels leave their counters */
