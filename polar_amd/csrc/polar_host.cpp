@@ -1503,24 +1503,40 @@ static int mc_step_launch(polar_code_t *h, int constellation, uint64_t seed, con
     if ((int)h->mc_slots.size() < n_L * n_slots) h->mc_slots.resize((size_t)n_L * n_slots);
     if ((rc = h->d_slot_n.ensure((size_t)n_L * n_slots))) return rc;
     h->h_slot_n.resize((size_t)n_L * n_slots);
-    for (int li = 0; li < n_L; ++li) {
-        long rows = 0;
-        for (const McStage &s : stages) {
-            if (s.li != li) continue;
-            polar_code::McSlot &sl = h->mc_slots[(size_t)li * n_slots + s.slot];
-            if (s.fresh) sl.cnt = (s.T - part + parts - 1) / parts;          // this device's trials of the round: base + part, + parts, ...
-            rows += sl.cnt;
-        }
-        if (rows == 0) continue;
+    // rows of every list size's merged batch (the buffers are sized once, for the largest: a reallocation between two list sizes
+    // would lose the rows they share, below)
+    std::vector<long> rows_of(n_L, 0);
+    long rows_max = 0;
+    for (const McStage &s : stages) {
+        polar_code::McSlot &sl = h->mc_slots[(size_t)s.li * n_slots + s.slot];
+        if (s.fresh) sl.cnt = (s.T - part + parts - 1) / parts;          // this device's trials of the round: base + part, + parts, ...
+        rows_of[s.li] += sl.cnt;
+        rows_max = std::max(rows_max, rows_of[s.li]);
+    }
+    if (rows_max > 0) {
         // (a quarter of headroom when the buffers grow: the first steps of a call carry one round, the later ones the survivors of
         // the rounds before as well — a 4-GiB reallocation in the middle of a sweep is a second lost)
-        const size_t cap_rows = (size_t)rows * N <= h->d_in.cap ? (size_t)rows : (size_t)rows + (size_t)rows / 4;
+        const size_t cap_rows = (size_t)rows_max * N <= h->d_in.cap ? (size_t)rows_max : (size_t)rows_max + (size_t)rows_max / 4;
         if ((rc = h->d_in.ensure(cap_rows * N))) return rc;
         if ((rc = h->d_out.ensure(cap_rows * K))) return rc;
         if ((rc = h->d_bytes_a.ensure(cap_rows * K))) return rc;      // sent info
+    }
+    // A trial's LLRs at a point do not depend on the list size (one noise vector per run, shared by every (L, Eb/N0):
+    // PolarCode.cpp:708-710), and the first stage of a round simulates ALL its trials: when the list sizes of a sweep start the
+    // same round at the same point (the reference's main.cpp: five list sizes), its rows are generated ONCE — they come first in
+    // the merged batch and stay where they are for the next list size, whose later stages are generated behind them.
+    const McStage *shared = nullptr;          // the fresh stage whose rows are in d_in / d_bytes_a [0, shared_cnt)
+    long shared_cnt = 0;
+    std::vector<const McStage *> ord;
+    for (int li = 0; li < n_L; ++li) {
+        const long rows = rows_of[li];
+        if (rows == 0) continue;
+        ord.clear();
+        for (const McStage &s : stages) if (s.li == li && s.fresh) ord.push_back(&s);
+        for (const McStage &s : stages) if (s.li == li && !s.fresh) ord.push_back(&s);
         long off = 0;
-        for (const McStage &s : stages) {
-            if (s.li != li) continue;
+        for (const McStage *sp : ord) {
+            const McStage &s = *sp;
             const size_t id = (size_t)li * n_slots + s.slot;
             polar_code::McSlot &sl = h->mc_slots[id];
             if (sl.cnt == 0) continue;
@@ -1529,18 +1545,22 @@ static int mc_step_launch(polar_code_t *h, int constellation, uint64_t seed, con
                 sl.cur = 0;
                 HIP_TRY(polar_launch_mc_init_alive(sl.list[0].p, h->d_slot_n.p + id, s.base + (uint64_t)part, parts, sl.cnt, st));
             }
-            PolarEncodeParams p;
-            fill_enc(h, p);
-            p.B = sl.cnt; p.seed = seed; p.sel = sl.list[sl.cur].p; p.n_dev = nullptr;
-            fill_channel(h, p, constellation, axis[s.ie]);
-            p.llr = h->d_in.p + (size_t)off * N; p.info_out = h->d_bytes_a.p + (size_t)off * K;
-            HIP_TRY(polar_launch_synth(p, st));
+            const bool reuse = s.fresh && off == 0 && shared && shared->ie == s.ie && shared->base == s.base && shared->T == s.T && shared_cnt == sl.cnt;
+            if (!reuse) {
+                PolarEncodeParams p;
+                fill_enc(h, p);
+                p.B = sl.cnt; p.seed = seed; p.sel = sl.list[sl.cur].p; p.n_dev = nullptr;
+                fill_channel(h, p, constellation, axis[s.ie]);
+                p.llr = h->d_in.p + (size_t)off * N; p.info_out = h->d_bytes_a.p + (size_t)off * K;
+                HIP_TRY(polar_launch_synth(p, st));
+                if (off == 0) { shared = s.fresh ? &s : nullptr; shared_cnt = sl.cnt; }     // (whatever is at row 0 now)
+            }
             off += sl.cnt;
         }
         if ((rc = decode_impl(h, h->d_in.p, 0, rows, nullptr, Ls[li], h->d_out.p, nullptr, st, nullptr, nullptr))) return rc;
         off = 0;
-        for (const McStage &s : stages) {
-            if (s.li != li) continue;
+        for (const McStage *sp : ord) {
+            const McStage &s = *sp;
             const size_t id = (size_t)li * n_slots + s.slot;
             polar_code::McSlot &sl = h->mc_slots[id];
             if (sl.cnt == 0) continue;
