@@ -249,11 +249,19 @@ def main():
     # bytes and the VALU occupancy come from the committed rocprofv3 PMC profile of this very command.
     lds_layers_w, lds_layers_r = 4, 3                       # layers written to / read from LDS (S <= 8 / S <= 4)
     lds_bytes = B * L * N * 8.0 * (lds_layers_w + 2 * lds_layers_r)
+    # measured: SQ_INSTS_LDS of the committed PMC pass (per-wave LDS instructions) x 64 lanes x 8 B — every LDS access of this
+    # kernel's node state is a ds_read_b64 / ds_write_b64 per lane (the wider ds_read_b128 of the byte stack and the 4-byte
+    # control words are a few per cent of the count and pull in opposite directions); modelled figure beside it
+    lds_meas = prof.get("lds_insts_per_launch") * 64 * 8.0 if prof.get("lds_insts_per_launch") else None
     res["roofline"]["lds"] = {
-        "modelled_bytes_per_launch": lds_bytes, "achieved": lds_bytes / kern_avg_s / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
-        "frac": lds_bytes / kern_avg_s / 1e9 / LDS_PEAK_GBS,
-        "lds_hit_fraction": (lds_bytes / (lds_bytes + traffic)) if traffic else None,
-        "note": "modelled upper bound; lds_hit_fraction = LDS bytes / (LDS + measured HBM bytes) of the decoder's working state",
+        "measured_bytes_per_launch": lds_meas, "measured_from": "SQ_INSTS_LDS x 64 lanes x 8 B (profiles/traffic.json, same library)" if lds_meas else None,
+        "modelled_bytes_per_launch": lds_bytes,
+        "achieved": (lds_meas or lds_bytes) / kern_avg_s / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
+        "frac": (lds_meas or lds_bytes) / kern_avg_s / 1e9 / LDS_PEAK_GBS,
+        "lds_hit_fraction": (lds_meas / (lds_meas + traffic)) if (traffic and lds_meas) else None,
+        "lds_hit_fraction_modelled": (lds_bytes / (lds_bytes + traffic)) if traffic else None,
+        "lds_bank_conflict_cycle_frac_in_profile": prof.get("lds_bank_conflict_frac"),
+        "note": "lds_hit_fraction = LDS bytes / (LDS + measured HBM bytes) of the decoder's working state, both from the rocprofv3 PMC passes of this library; the modelled figure is the schedule's upper bound",
     }
     res["roofline"]["valu"] = {
         "busy_frac_in_profile": prof.get("valu_busy_frac_in_profile"),
@@ -277,6 +285,12 @@ def main():
             torch.cuda.synchronize()
     if shared:
         res["shared_gpu_test"] = True
+    if world > 1:
+        # what really reduced the counters: the ranks of the process group and its backend, and whether the native leg's
+        # single-process driver went through RCCL (false = host-side sum: e.g. one GPU standing in for several)
+        res["rccl_ranks_seen"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                                  "distinct_devices": len(set(gather_device_ids(dist, local_rank, shared))),
+                                  "native_multi_used_rccl": res.get("monte_carlo", {}).get("native_multi", {}).get("used_rccl")}
     hung = bool(res.get("monte_carlo", {}).get("native_multi_hung"))
     def guarded(name, fn):
         """The records beside the headline must not be able to take the result line with them: a failure in one of them is
@@ -302,6 +316,18 @@ def main():
         emit_last_line(json.dumps(res))        # the ONE JSON line, last thing on stdout
         if res.get("monte_carlo", {}).get("native_multi_hung"):
             os._exit(0)                        # (a thread is still inside the library: no orderly teardown)
+
+
+def gather_device_ids(dist, local_rank, shared):
+    """The (host-visible) GPU index every rank of the launch really computes on."""
+    t = torch.zeros(dist.get_world_size(), dtype=torch.int64)
+    t[dist.get_rank()] = local_rank
+    if shared or dist.get_backend() == "gloo":
+        dist.all_reduce(t)
+        return [int(x) for x in t]
+    d = t.to(torch.device("cuda", local_rank))
+    dist.all_reduce(d)
+    return [int(x) for x in d.cpu()]
 
 
 def emit_last_line(line):
@@ -414,12 +440,15 @@ def monte_carlo_leg(args, code, dist, dev, rank, world, engine=None, native=True
                 t0 = time.perf_counter()
                 b2, c2 = code.get_bler_quick(MC_GRID, Ls, max_runs=total, max_err=no_stop, seed=args.seed, batch=per_round, devices=devs, return_counters=True)
                 dt2 = time.perf_counter() - t0
+                # (the step times of THIS call: the prefix call below overwrites the handle's record)
+                step_ms = {k: code.debug_get("round_us_" + k) / 1e3 for k in ("first", "min", "median", "max")}
+                steps2, used2 = code.debug_get("round_us_count"), bool(code.last_used_rccl)
                 _, c3 = code.get_bler_quick(MC_GRID, Ls, max_runs=MC_PREFIX, max_err=no_stop, seed=args.seed, batch=MC_PREFIX, devices=devs, return_counters=True)
                 box["equal"] = bool(np.array_equal(e_one, c3["err"]) and np.array_equal(r_one, c3["run"]))
                 box["rec"] = {"driver": "polar_get_bler_quick_multi_ex from rank 0: one worker thread, stream and table clone per GPU, rounds pipelined, "
-                                        "ncclAllReduce(uint64, sum) per step" + ("" if code.last_used_rccl else " (host-side sum: RCCL not used)"),
-                              "seconds": dt2, "mc_trials_per_s": total / dt2, "rounds": c2["rounds"], "used_rccl": bool(code.last_used_rccl),
-                              "step_ms": {k: code.debug_get("round_us_" + k) / 1e3 for k in ("first", "min", "median", "max")},
+                                        "ncclAllReduce(uint64, sum) per step" + ("" if used2 else " (host-side sum: RCCL not used)"),
+                              "seconds": dt2, "mc_trials_per_s": total / dt2, "rounds": c2["rounds"], "steps": steps2, "used_rccl": used2,
+                              "devices": len(devs), "step_ms": step_ms, "step_ms_mean": dt2 * 1e3 / max(steps2, 1),
                               "bler": [float(x) for x in b2[0]], "block_errors": [int(x) for x in c2["err"][0]],
                               "equals_multiprocess_counters": bool(np.array_equal(c2["err"], err) and np.array_equal(c2["run"], run))}
             except Exception as ex:                              # (the headline above must be printed whatever happens here)
@@ -490,6 +519,9 @@ def dry_run(args, world, rank):
             def debug_set(self, k, v):
                 pass
 
+            def debug_get(self, k):
+                return 0
+
         a2 = argparse.Namespace(**vars(args))
         a2.mc_trials = min(args.mc_trials, 8 * 262144 * world)
         mc = monte_carlo_leg(a2, _One(), dist, None, rank, world, engine=engine, native=True)
@@ -501,6 +533,7 @@ def dry_run(args, world, rank):
         emit_last_line(json.dumps({"metric": "codewords/s (N=2048 K=1024 L=32 LLR-SCL)", "value": None, "unit": "codewords/s",
                                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
                                    "runs_all_ranks": int(counters[1]), "scaling": "weak", "monte_carlo": mc,
+                                   "rccl_ranks_seen": {"world_size": world, "backend": "gloo", "distinct_devices": 0, "native_multi_used_rccl": None},
                                    "config": {"workload": "dry run (gloo, CPU): launcher and counter reduction only"}}))
 
 
@@ -566,12 +599,14 @@ def cpu_baseline(args, code, llr, out):
     [x.join() for x in th]
     dt2 = time.perf_counter() - t
     mism2 = int((want2 != out[:sample2].cpu().numpy()).any(axis=1).sum())
+    full = cpu_full_trial(args, kind)
     return {
         "value": sample / dt,
         "unit": "codewords/s",
         "cores": 1,
         "host_cores_available": os.cpu_count(),
         "kind": kind,
+        "full_trial": full,
         "sample": f"first {sample} codewords of the benchmark batch, decode_scl_llr only, single thread",
         "gpu_vs_cpu_mismatching_codewords": mism,
         "all_cores": {
@@ -581,6 +616,28 @@ def cpu_baseline(args, code, llr, out):
             "gpu_vs_cpu_mismatching_codewords": mism2,
         },
     }
+
+
+def cpu_full_trial(args, kind):
+    """SURVEY §8(d) "single-thread full trial": the reference's OWN Monte-Carlo loop (PolarCode::get_bler_quick,
+    PolarCode.cpp:696-775: info bits, encode, BPSK, AWGN, LLRs, decode, compare) timed on one host core at ONE point of the
+    benchmark's Eb/N0 — its constants are compiled in (max_runs = 1000, max_err = 100, .cpp:661-662), so the number of trials
+    it ran follows from the BLER it returns: 1000 when it never stopped early, else the trial at which the 101st error
+    fell (errors / bler). With the restatement (kind "port") the same loop with the same constants."""
+    import oracle_lib
+    if kind == "reference":
+        cpu = oracle_lib.Reference(args.n, args.K, 0.32, args.crc, srand=1)
+        fn = lambda: cpu.get_bler_quick([args.ebno], [args.L])
+    else:
+        cpu = oracle_lib.Oracle(args.n, args.K, 0.32, args.crc, srand=1)
+        fn = lambda: cpu.get_bler_quick_ref([args.ebno], [args.L], 1000, 100)
+    t = time.perf_counter()
+    bler = float(fn()[0][0])
+    dt = time.perf_counter() - t
+    runs = 1000 if bler * 1000 <= 100.5 else int(round(101 / bler))
+    return {"value": runs / dt, "unit": "trials/s", "cores": 1, "kind": kind, "trials": runs, "seconds": dt, "bler": bler,
+            "sample": f"get_bler_quick([{args.ebno}], [{args.L}]) of the CPU side: the reference's whole loop (generation, encoder, channel, "
+                      f"LLRs, decode, compare), its own constants max_runs = 1000, max_err = 100"}
 
 
 def lib_sha256():

@@ -83,13 +83,18 @@ classdef PolarCode < handle
         function u = decode_scl_p1(obj, p1, p0, list_size)
             u = double(polar_mex('decode_scl_p1', obj.h, double(p1(:)'), double(p0(:)'), list_size));
         end
-        function u = decode_scl_llr(obj, llr, list_size)
-            % llr may be 1 x N, B x N (one codeword per row -> u is B x K) or N x B (one codeword per COLUMN -> u is K x B:
-            % MATLAB's column-major storage is then the library's and nothing is transposed on either side — the layout
-            % for large batches); double or single (single halves the bytes that cross the PCIe link). One GPU batch;
-            % from 32 MiB of LLRs on the library pipelines the copy and the decode.
+        function u = decode_scl_llr(obj, llr, list_size, layout)
+            % llr may be 1 x N (u is 1 x K, as the reference), B x N (one codeword per row -> u is B x K) or N x B (one codeword
+            % per COLUMN -> u is K x B: MATLAB's column-major storage is then the library's and nothing is transposed on either
+            % side — the layout for large batches); double or single (single halves the bytes that cross the PCIe link).
+            % layout (optional): 'rows' or 'cols' names the layout; it is REQUIRED for a square N x N batch, which fits both
+            % (the gateway refuses to guess). One GPU batch; from 32 MiB of LLRs on the library pipelines copy and decode.
             if ~isa(llr, 'single'), llr = double(llr); end
-            u = double(polar_mex('decode_scl_llr', obj.h, llr, list_size));
+            if nargin < 4
+                u = double(polar_mex('decode_scl_llr', obj.h, llr, list_size));
+            else
+                u = double(polar_mex('decode_scl_llr', obj.h, llr, list_size, layout));
+            end
         end
         function [bler, ber] = get_bler_quick(obj, ebno_vec, list_size_vec, max_runs, max_err, seed, devices, constellation_id)
             % [bler, ber] indexed (i_ebno, i_list) as PolarM (:781-850); PolarM constants max_err=50, max_runs=500

@@ -58,9 +58,15 @@ void colmajor_from_rows(const T *y, size_t B, size_t N, T *x, unsigned threads =
     for (auto &q : th) q.join();
 }
 // how a 2-D argument of `rows` x `cols` holds codewords of length N: 'c' = one per column (N x B), 'r' = one per row (B x N;
-// also a single 1 x N or N x 1 vector), 0 = neither. A square N x N argument is read as B x N (rows), as round 4 did.
-inline char batch_layout(size_t rows, size_t cols, size_t N, size_t *B) {
-    if (rows * cols == N && (rows == 1 || cols == 1)) { *B = 1; return 'r'; }
+// also a single 1 x N or N x 1 vector), 0 = neither. `want` ('r' / 'c' / 0) is the caller's explicit choice: the shape must
+// then fit it. Without one the shape decides; a square N x N argument fits both — *ambiguous is set and the caller refuses it
+// (round 5 read it as rows, silently: 2048 codewords stored as columns came back as wrong bits).
+inline char batch_layout(size_t rows, size_t cols, size_t N, char want, size_t *B, bool *ambiguous) {
+    *ambiguous = false;
+    if (rows * cols == N && (rows == 1 || cols == 1)) { *B = 1; return want ? want : 'r'; }      // (one vector is one codeword either way)
+    if (want == 'r') { if (cols != N) return 0; *B = rows; return 'r'; }
+    if (want == 'c') { if (rows != N) return 0; *B = cols; return 'c'; }
+    if (cols == N && rows == N) { *B = N; *ambiguous = true; return 'r'; }
     if (cols == N) { *B = rows; return 'r'; }
     if (rows == N) { *B = cols; return 'c'; }
     return 0;

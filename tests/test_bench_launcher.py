@@ -31,6 +31,9 @@ def test_plain_launch_with_gpus_2_runs_two_ranks():
     assert mc["multiprocess"]["rounds"] == 4194304 // (2 * 262144)
     assert mc["multiprocess"]["runs"] == [4194304] * 5 and mc["mc_trials_per_s"] > 0
     assert mc["counters_equal_single_gpu"] is True and mc["counters_equal_single_gpu_detail"]["multiprocess"] is True
+    # round 6: the line says who reduced the counters (ranks of the process group, its backend, the native leg's RCCL flag)
+    seen = line["rccl_ranks_seen"]
+    assert seen["world_size"] == 2 and seen["backend"] == "gloo" and "native_multi_used_rccl" in seen
 
 
 def test_world_size_and_gpus_must_agree():

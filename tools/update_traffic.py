@@ -27,5 +27,9 @@ if "GRBM_GUI_ACTIVE" in c and "SQ_ACTIVE_INST_VALU" in c:
     out["valu_busy_frac_in_profile"] = c["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] * 4.0 / (1024.0 * cyc)
 if "SQ_INSTS_VALU" in c:
     out["valu_insts_per_wave_decode"] = c["SQ_INSTS_VALU"]["mean_per_launch"] / (batch / 2.0)     # L = 32: two codewords per wave
+if "SQ_INSTS_LDS" in c:
+    out["lds_insts_per_launch"] = c["SQ_INSTS_LDS"]["mean_per_launch"]
+if "SQ_LDS_BANK_CONFLICT" in c and "SQ_ACTIVE_INST_LDS" in c and c["SQ_ACTIVE_INST_LDS"]["mean_per_launch"] > 0:
+    out["lds_bank_conflict_frac"] = c["SQ_LDS_BANK_CONFLICT"]["mean_per_launch"] / c["SQ_ACTIVE_INST_LDS"]["mean_per_launch"]
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)
 print(out)
