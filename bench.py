@@ -135,9 +135,15 @@ def main():
     if rank == 0 and not os.environ.get("POLAR_AMD_LIB"):
         build.build()            # in-tree .so normally travels prebuilt; only one rank may compile
                                  # (an explicit POLAR_AMD_LIB — A/B runs — is used as it is)
+        if shared:
+            build.build_test()
     if dist:
         dist.barrier()
     import polar_amd
+    if shared:
+        # TEST MODE only: one GPU stands in for several ("share_device", a fault-injection hook that exists only in the test
+        # build of the library: include/polar_amd_debug.h)
+        polar_amd.use_library(build.LIB_TEST)
 
     # the code: Bhattacharyya construction as the reference's main.cpp (eps = 0.32); the CRC matrix
     # comes from glibc rand() after srand(1) — identical on every rank

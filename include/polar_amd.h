@@ -168,9 +168,9 @@ int polar_get_bler_quick_ber(polar_code_t *h, const double *ebno, int n_e, const
  * ncclAllReduce(uint64, sum) over xGMI (bound at run time; a host-side sum when RCCL cannot be loaded, or with
  * POLAR_NO_RCCL set when the handle was created). Counter-based inputs make the counters independent of n_dev for a given
  * `batch` (the automatic rounds grow with the device count: 262144 trials per device). *used_rccl (optional) reports
- * which path summed the counters. ber_out may be NULL. A device may be listed once; the test hook "share_device"
- * (polar_debug_set) lifts that so that one GPU can stand in for several (separate contexts and worker threads, host-side
- * sum). One worker thread per device lives on the handle between calls (created with the communicators). */
+ * which path summed the counters. ber_out may be NULL. A device may be listed once (the test build of the library has a hook
+ * that lifts this so that one GPU can stand in for several: include/polar_amd_debug.h). One worker thread per device lives on
+ * the handle between calls (created with the communicators). */
 int polar_get_bler_quick_multi(polar_code_t *h, const int *devices, int n_dev, const double *ebno, int n_e,
                                const uint8_t *L, int n_L, long max_runs, long max_err, uint64_t seed, long batch,
                                double *bler_out, double *ber_out, int *used_rccl);
@@ -188,7 +188,7 @@ int polar_get_bler_quick_multi(polar_code_t *h, const int *devices, int n_dev, c
  * loop; the counters are reduced once per step.
  * Failure handling: a device that fails before the step's collective keeps every device out of it; a device whose
  * collective enqueue fails makes every device abort its communicator before it waits; a step that exceeds the watchdog
- * (1800 s; polar_debug_set "multi_timeout_s") is ended in three bounded stages ("multi_grace_s", 10 s each): the workers are
+ * (1800 s; include/polar_amd_debug.h "multi_timeout_s") is ended in three bounded stages ("multi_grace_s", 10 s each): the workers are
  * signalled and abort their own communicators, what is left is aborted from the calling thread, and a worker that still does
  * not answer is given up — the call returns, the handle accepts no further get_bler_quick* calls and polar_destroy frees
  * nothing of it. Otherwise the call returns POLAR_E_DEVICE and the next call rebuilds the communicators. */
@@ -200,17 +200,14 @@ int polar_get_bler_quick_multi_ex(polar_code_t *h, int constellation, const int 
 /* The same sweep with the trials shared by `world` PROCESSES (one per GPU, as a process-group or MPI launcher starts them): this process is
  * `rank`, its handle's device simulates the trials rank, rank + world, ... of every round, and after every step `reduce` is
  * called — collectively, on every rank, the same number of times — to SUM the n uint64 counters in place over the ranks
- * (e.g. an all-reduce of the process group; return non-zero to fail the call). Counters, estimates and rounds are those of
+ * (e.g. an all-reduce of the process group; return non-zero to fail the call). A rank whose own step failed (launch error,
+ * watchdog) still makes this call once, with a failure flag in the last counter: every rank then returns POLAR_E_DEVICE from
+ * the same step and none is left waiting in the collective. Counters, estimates and rounds are those of
  * polar_get_bler_quick_multi_ex with world devices. polar_amd/montecarlo.py drives it with its process group's all-reduce. */
 typedef int (*polar_reduce_fn)(void *user, uint64_t *counters, int n);
 int polar_get_bler_quick_rank(polar_code_t *h, int constellation, int rank, int world, polar_reduce_fn reduce, void *user,
                               const double *axis, int n_e, const uint8_t *L, int n_L, long max_runs, long max_err, uint64_t seed,
                               long batch, double *bler_out, double *ber_out, uint64_t *err_out, uint64_t *run_out, long *rounds_out);
-
-/* test hook: number of ncclCommInitAll calls made by this library so far (the communicators and streams of a device
- * list are cached on the handle: a second polar_get_bler_quick_multi with the same list makes none). When a device's
- * round fails, no device enters the round's collective, the communicators are aborted and the call returns the error. */
-int polar_debug_comm_inits(void);
 
 /* step-wise Monte-Carlo for multi-GPU drivers: simulate trials {t0 + i*stride : i < T} for
  * every enabled (L, Eb/N0) point and ADD to err/run (host uint64 [n_L*n_e]). */
@@ -269,22 +266,9 @@ int polar_set_mode(polar_code_t *h, int mode);
  * weak leaves are accepted, but their decoded bits are the reference's only as far as the LLR-domain kernel reproduces
  * glibc's rounding noise: polar_create_explicit() reports POLAR_W_WEAK_LEAVES (a positive, non-error status; the handle is
  * valid) and this function the count. */
-int polar_debug_weak_leaves(const polar_code_t *h);
-/* test / measurement hooks. polar_debug_set: the knobs above after creation ("mode_override" -1|0|1|2, "sc_no_fold",
- * "no_tables", "no_prefix", "no_rccl", "force_rccl"; "lat_max_b": largest batch that takes the one-codeword-per-wave kernels,
- * 0 = default, -1 = never) and the ones that deliberately have NO environment form: "share_device" (one GPU
- * may be listed several times in a device list), "fail_device" = d / "fail_collective" = d (worker d reports a failure in
- * its second round before / after the barrier that precedes the counter reduction; -1 = off), "multi_timeout_s".
- * polar_debug_get: "allocs" (hipMalloc calls of all handles' scratch so far), "comm_inits", "weak_leaves",
- * "last_rounds", "last_round_max_per_device", "worker_threads_started" (of the handle's last get_bler_quick* calls).
- * "multi_grace_s", "force_workers", "stall_device" / "stall_ms" (watchdog tests), "host_pipe_min_bytes" / "host_chunk_bytes" /
- * "host_lanes" / "host_threads" / "host_ramp" (the pipelined host-pointer path; polar_debug_get "host_chunks", "host_chunk_cw",
- * "host_lanes", "host_threads", "host_us_*"), polar_debug_get "round_us_first|min|median|max|count" (steps of the last sweep),
- * "multi_poisoned". Like every entry point, the hooks must not run concurrently with another call on the same handle; the knobs
- * that shape the cached multi-device context ("no_rccl", "force_rccl", "share_device", "force_workers") drop it. */
-int polar_debug_set(polar_code_t *h, const char *key, long value);
-long polar_debug_get(const polar_code_t *h, const char *key);
-void *polar_debug_scratch_ptr(polar_code_t *h);      /* measurement builds only: where instrumented kernels leave their counters */
+int polar_get_weak_leaves(const polar_code_t *h);
+/* Measurement knobs and test hooks (polar_debug_set / polar_debug_get / ...) are NOT part of this interface: they are declared
+ * in include/polar_amd_debug.h, and the fault-injection hooks among them exist only in the test build of the library. */
 
 #ifdef __cplusplus
 }

@@ -67,6 +67,16 @@ def lib():
     return _lib
 
 
+def use_library(path=None):
+    """Load another build of the library for everything created from now on (None = the product again). Handles belong to the
+    library that made them: the caller keeps none across the switch. The tests of the failure protocol load the test build
+    (libpolar_amd_test.so: the fault-injection hooks of include/polar_amd_debug.h exist only there)."""
+    global _lib, LIB_PATH
+    LIB_PATH = path or os.environ.get("POLAR_AMD_LIB") or os.path.join(_HERE, "libpolar_amd.so")
+    _lib = None
+    return lib()
+
+
 def _check(rc):
     """Negative = error; positive = a non-error status (POLAR_W_WEAK_LEAVES), returned to the caller."""
     if rc < 0:
@@ -97,29 +107,29 @@ class PolarCode:
     """
 
     def __init__(self, num_layers, info_length, epsilon, crc_size=0, _handle=None):
-        L = lib()
+        L = self._L = lib()          # (a handle belongs to the library that made it: use_library() may switch the default later)
         self._h = C.c_void_p()
         if _handle is not None:
             self._h = _handle
         else:
-            _check(L.polar_create(C.c_int(num_layers), C.c_int(info_length), C.c_double(epsilon),
+            self._chk(L.polar_create(C.c_int(num_layers), C.c_int(info_length), C.c_double(epsilon),
                                   C.c_int(crc_size), C.byref(self._h)))
         n, N, K, crc = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-        _check(L.polar_get_params(self._h, C.byref(n), C.byref(N), C.byref(K), C.byref(crc)))
+        self._chk(L.polar_get_params(self._h, C.byref(n), C.byref(N), C.byref(K), C.byref(crc)))
         self.n, self.block_length, self.info_length, self.crc_size = n.value, N.value, K.value, crc.value
         self.N, self.K = self.block_length, self.info_length
 
     @property
     def weak_leaves(self):
-        """Unfrozen leaves the handle classified as weak at creation (polar_debug_weak_leaves)."""
-        return int(lib().polar_debug_weak_leaves(self._h))
+        """Unfrozen leaves the handle classified as weak at creation (polar_get_weak_leaves)."""
+        return int(self._L.polar_get_weak_leaves(self._h))
 
     def debug_set(self, key, value):
-        """Test / measurement hooks of include/polar_amd.h (polar_debug_set)."""
-        _check(lib().polar_debug_set(self._h, key.encode(), C.c_long(int(value))))
+        """Measurement knobs / test hooks of include/polar_amd_debug.h (polar_debug_set)."""
+        self._chk(self._L.polar_debug_set(self._h, key.encode(), C.c_long(int(value))))
 
     def debug_get(self, key):
-        f = lib().polar_debug_get
+        f = self._L.polar_debug_get
         f.restype = C.c_long
         return int(f(self._h, key.encode()))
 
@@ -217,9 +227,14 @@ class PolarCode:
         self.construction_counts, self.bler_estimate = new.construction_counts, new.bler_estimate
         return self.bler_estimate
 
+    def _chk(self, rc):
+        if rc < 0:
+            raise PolarError(f"polar_amd error {rc}: {self._L.polar_last_error().decode()}")
+        return rc
+
     def close(self):
         if getattr(self, "_h", None):
-            lib().polar_destroy(self._h)
+            self._L.polar_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -232,26 +247,26 @@ class PolarCode:
     @property
     def frozen_bits(self):
         a = np.zeros(self.N, np.uint8)
-        _check(lib().polar_get_frozen(self._h, _p(a, _u8p)))
+        self._chk(self._L.polar_get_frozen(self._h, _p(a, _u8p)))
         return a
 
     @property
     def channel_order_descending(self):
         a = np.zeros(self.N, np.uint16)
-        _check(lib().polar_get_order(self._h, _p(a, _u16p)))
+        self._chk(self._L.polar_get_order(self._h, _p(a, _u16p)))
         return a
 
     @property
     def bit_rev_order(self):
         a = np.zeros(self.N, np.uint16)
-        _check(lib().polar_get_bitrev(self._h, _p(a, _u16p)))
+        self._chk(self._L.polar_get_bitrev(self._h, _p(a, _u16p)))
         return a
 
     @property
     def crc_matrix(self):
         a = np.zeros((self.crc_size, self.K), np.uint8)
         if self.crc_size:
-            _check(lib().polar_get_crc_matrix(self._h, _p(a, _u8p)))
+            self._chk(self._L.polar_get_crc_matrix(self._h, _p(a, _u8p)))
         return a
 
     @crc_matrix.setter
@@ -260,21 +275,21 @@ class PolarCode:
         if m.shape != (self.crc_size, self.K):
             raise PolarError("crc_matrix must be crc x K")
         if self.crc_size:
-            _check(lib().polar_set_crc_matrix(self._h, _p(m, _u8p)))
+            self._chk(self._L.polar_set_crc_matrix(self._h, _p(m, _u8p)))
 
     def reserve(self, B, list_size):
         """Pre-size the device scratch for decodes of up to B codewords at this list size (polar_reserve)."""
-        _check(lib().polar_reserve(self._h, C.c_long(B), C.c_int(list_size)))
+        self._chk(self._L.polar_reserve(self._h, C.c_long(B), C.c_int(list_size)))
 
     def set_tuning(self, waves_per_cu=0, lds_log=0):
-        _check(lib().polar_set_tuning(self._h, C.c_int(waves_per_cu), C.c_int(lds_log)))
+        self._chk(self._L.polar_set_tuning(self._h, C.c_int(waves_per_cu), C.c_int(lds_log)))
 
     def set_mode(self, mode=0):
         """Node arithmetic of decode_scl_llr: 0 automatic, 1 LLR-domain kernel, 2 exp-domain kernel (+ fallback pass)."""
-        _check(lib().polar_set_mode(self._h, C.c_int(mode)))
+        self._chk(self._L.polar_set_mode(self._h, C.c_int(mode)))
 
     def snr_sqrt_linear(self, ebno_db):
-        return lib().polar_snr_sqrt_linear(self._h, C.c_double(ebno_db))
+        return self._L.polar_snr_sqrt_linear(self._h, C.c_double(ebno_db))
 
     # ---- encode (PolarCode.cpp:60-91) ---------------------------------------------------
     def encode(self, info_bits):
@@ -282,7 +297,7 @@ class PolarCode:
         single = info.ndim == 1
         info2 = info.reshape(-1, self.K)
         out = np.zeros((info2.shape[0], self.N), np.uint8)
-        _check(lib().polar_encode_batch(self._h, _p(info2, _u8p), C.c_long(info2.shape[0]), _p(out, _u8p)))
+        self._chk(self._L.polar_encode_batch(self._h, _p(info2, _u8p), C.c_long(info2.shape[0]), _p(out, _u8p)))
         return out[0] if single else out
 
     # ---- decoders -----------------------------------------------------------------------
@@ -300,16 +315,16 @@ class PolarCode:
         elif out.dtype != np.uint8 or out.shape != (a2.shape[0], self.K) or not out.flags.c_contiguous:
             raise PolarError("out must be a C-contiguous uint8 array of shape [B, K]")
         if f32:
-            _check(lib().polar_decode_scl_llr_batch_f32(self._h, _p(a2, C.POINTER(C.c_float)), C.c_long(a2.shape[0]),
+            self._chk(self._L.polar_decode_scl_llr_batch_f32(self._h, _p(a2, C.POINTER(C.c_float)), C.c_long(a2.shape[0]),
                                                         C.c_int(list_size), _p(out, _u8p)))
         else:
-            _check(lib().polar_decode_scl_llr_batch(self._h, _p(a2, _dp), C.c_long(a2.shape[0]), C.c_int(list_size),
+            self._chk(self._L.polar_decode_scl_llr_batch(self._h, _p(a2, _dp), C.c_long(a2.shape[0]), C.c_int(list_size),
                                                     _p(out, _u8p)))
         return out[0] if single else out
 
     def decode_scl_llr_dev_f32(self, llr_ptr, B, list_size, out_ptr, pm_ptr=0, stream=None):
         """Device-resident float32 LLRs [B, N] -> uint8 [B, K]; asynchronous on `stream`."""
-        _check(lib().polar_decode_scl_llr_batch_dev_f32(self._h, C.c_void_p(llr_ptr), C.c_long(B), C.c_int(list_size),
+        self._chk(self._L.polar_decode_scl_llr_batch_dev_f32(self._h, C.c_void_p(llr_ptr), C.c_long(B), C.c_int(list_size),
                                                         C.c_void_p(out_ptr), C.c_void_p(pm_ptr), _stream_ptr(stream)))
 
     def decode_scl_p1(self, p1, p0, list_size):
@@ -319,7 +334,7 @@ class PolarCode:
         single = a.ndim == 1
         a2, b2 = a.reshape(-1, self.N), b.reshape(-1, self.N)
         out = np.zeros((a2.shape[0], self.K), np.uint8)
-        _check(lib().polar_decode_scl_p1_batch(self._h, _p(a2, _dp), _p(b2, _dp), C.c_long(a2.shape[0]),
+        self._chk(self._L.polar_decode_scl_p1_batch(self._h, _p(a2, _dp), _p(b2, _dp), C.c_long(a2.shape[0]),
                                                C.c_int(list_size), _p(out, _u8p)))
         return out[0] if single else out
 
@@ -329,7 +344,7 @@ class PolarCode:
         single = a.ndim == 1
         a2 = a.reshape(-1, self.N)
         out = np.zeros((a2.shape[0], self.K), np.float64)
-        _check(lib().polar_decode_sc_p1_batch(self._h, _p(a2, _dp), C.c_long(a2.shape[0]), _p(out, _dp)))
+        self._chk(self._L.polar_decode_sc_p1_batch(self._h, _p(a2, _dp), C.c_long(a2.shape[0]), _p(out, _dp)))
         return out[0] if single else out
 
     # names used by BASELINE.json's north_star
@@ -341,20 +356,20 @@ class PolarCode:
     def decode_scl_llr_dev(self, llr_ptr, B, list_size, out_ptr, pm_ptr=0, stream=None, ev_start=0, ev_stop=0):
         """ev_start / ev_stop: raw hipEvent_t handles (e.g. torch.cuda.Event(...).cuda_event) recorded
         immediately around the dominant kernel's launch."""
-        _check(lib().polar_decode_scl_llr_batch_dev_ev(self._h, C.c_void_p(llr_ptr), C.c_long(B), C.c_int(list_size),
+        self._chk(self._L.polar_decode_scl_llr_batch_dev_ev(self._h, C.c_void_p(llr_ptr), C.c_long(B), C.c_int(list_size),
                                                        C.c_void_p(out_ptr), C.c_void_p(pm_ptr), _stream_ptr(stream),
                                                        C.c_void_p(ev_start), C.c_void_p(ev_stop)))
 
     def synth_llr_dev(self, seed, trial0, B, s, llr_ptr, info_ptr=0, stream=None):
-        _check(lib().polar_synth_llr_dev(self._h, C.c_uint64(seed), C.c_uint64(trial0), C.c_long(B), C.c_double(s),
+        self._chk(self._L.polar_synth_llr_dev(self._h, C.c_uint64(seed), C.c_uint64(trial0), C.c_long(B), C.c_double(s),
                                          C.c_void_p(llr_ptr), C.c_void_p(info_ptr), _stream_ptr(stream)))
 
     def count_errors_dev(self, a_ptr, b_ptr, B, counter_ptr, stream=None):
-        _check(lib().polar_count_errors_dev(self._h, C.c_void_p(a_ptr), C.c_void_p(b_ptr), C.c_long(B),
+        self._chk(self._L.polar_count_errors_dev(self._h, C.c_void_p(a_ptr), C.c_void_p(b_ptr), C.c_long(B),
                                             C.c_void_p(counter_ptr), _stream_ptr(stream)))
 
     def encode_dev(self, info_ptr, B, coded_ptr, stream=None):
-        _check(lib().polar_encode_batch_dev(self._h, C.c_void_p(info_ptr), C.c_long(B), C.c_void_p(coded_ptr),
+        self._chk(self._L.polar_encode_batch_dev(self._h, C.c_void_p(info_ptr), C.c_long(B), C.c_void_p(coded_ptr),
                                             _stream_ptr(stream)))
 
     # ---- Monte-Carlo (PolarCode.cpp:658-785) ---------------------------------------------
@@ -363,12 +378,12 @@ class PolarCode:
         Ls = np.ascontiguousarray(list_size_vec, np.uint8)
         enabled = np.ascontiguousarray(enabled, np.uint8)
         assert err.dtype == np.uint64 and run.dtype == np.uint64
-        _check(lib().polar_mc_batch(self._h, C.c_uint64(seed), C.c_uint64(t0), C.c_long(T), C.c_long(stride),
+        self._chk(self._L.polar_mc_batch(self._h, C.c_uint64(seed), C.c_uint64(t0), C.c_long(T), C.c_long(stride),
                                     _p(ebno, _dp), C.c_int(len(ebno)), _p(Ls, _u8p), C.c_int(len(Ls)),
                                     _p(enabled, _u8p), _p(err, _u64p), _p(run, _u64p)))
 
     def synth_bicm_llr_dev(self, constellation, seed, trial0, B, snr_db, llr_ptr, info_ptr=0, stream=None):
-        _check(lib().polar_synth_bicm_llr_dev(self._h, C.c_int(_constellation_id(constellation)), C.c_uint64(seed), C.c_uint64(trial0),
+        self._chk(self._L.polar_synth_bicm_llr_dev(self._h, C.c_int(_constellation_id(constellation)), C.c_uint64(seed), C.c_uint64(trial0),
                                               C.c_long(B), C.c_double(snr_db), C.c_void_p(llr_ptr),
                                               C.c_void_p(info_ptr), _stream_ptr(stream)))
 
@@ -377,7 +392,7 @@ class PolarCode:
         Ls = np.ascontiguousarray(list_size_vec, np.uint8)
         enabled = np.ascontiguousarray(enabled, np.uint8)
         assert err.dtype == np.uint64 and run.dtype == np.uint64
-        _check(lib().polar_mc_batch_bicm(self._h, C.c_int(_constellation_id(constellation)), C.c_uint64(seed), C.c_uint64(t0), C.c_long(T),
+        self._chk(self._L.polar_mc_batch_bicm(self._h, C.c_int(_constellation_id(constellation)), C.c_uint64(seed), C.c_uint64(t0), C.c_long(T),
                                          C.c_long(stride), _p(snr, _dp), C.c_int(len(snr)), _p(Ls, _u8p),
                                          C.c_int(len(Ls)), _p(enabled, _u8p), _p(err, _u64p), _p(run, _u64p)))
 
@@ -386,7 +401,7 @@ class PolarCode:
         Ls = np.ascontiguousarray(list_size_vec, np.uint8)
         enabled = np.ascontiguousarray(enabled, np.uint8)
         assert err.dtype == np.uint64 and run.dtype == np.uint64 and bit_err.dtype == np.uint64
-        _check(lib().polar_mc_batch_ber(self._h, C.c_uint64(seed), C.c_uint64(t0), C.c_long(T), C.c_long(stride),
+        self._chk(self._L.polar_mc_batch_ber(self._h, C.c_uint64(seed), C.c_uint64(t0), C.c_long(T), C.c_long(stride),
                                         _p(ebno, _dp), C.c_int(len(ebno)), _p(Ls, _u8p), C.c_int(len(Ls)),
                                         _p(enabled, _u8p), _p(err, _u64p), _p(bit_err, _u64p), _p(run, _u64p)))
 
@@ -415,7 +430,7 @@ class PolarCode:
         else:
             dptr, nd = None, 1
         used, rounds = C.c_int(0), C.c_long(0)
-        _check(lib().polar_get_bler_quick_multi_ex(self._h, C.c_int(cid), dptr, C.c_int(nd),
+        self._chk(self._L.polar_get_bler_quick_multi_ex(self._h, C.c_int(cid), dptr, C.c_int(nd),
                                                    _p(ebno, _dp), C.c_int(len(ebno)), _p(Ls, _u8p), C.c_int(len(Ls)),
                                                    C.c_long(max_runs), C.c_long(max_err), C.c_uint64(seed), C.c_long(batch),
                                                    _p(out, _dp), _p(ber, _dp), _p(err, _u64p), _p(run, _u64p),
@@ -449,7 +464,7 @@ class PolarCode:
                 failure.append(ex)
                 return 1
         cid = 0 if constellation is None else _constellation_id(constellation)
-        rc = lib().polar_get_bler_quick_rank(self._h, C.c_int(cid), C.c_int(rank), C.c_int(world), cb, None,
+        rc = self._L.polar_get_bler_quick_rank(self._h, C.c_int(cid), C.c_int(rank), C.c_int(world), cb, None,
                                              _p(ebno, _dp), C.c_int(len(ebno)), _p(Ls, _u8p), C.c_int(len(Ls)),
                                              C.c_long(max_runs), C.c_long(max_err), C.c_uint64(seed), C.c_long(batch or 0),
                                              _p(out, _dp), _p(ber, _dp), _p(err, _u64p), _p(run, _u64p), C.byref(rounds))

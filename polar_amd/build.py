@@ -24,7 +24,13 @@ FLAGS_LIST32 = ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause", "-mllvm", 
 SOURCES = [("polar_kernels.hip", ["POLAR_ED_TU=0"], "", []), ("polar_kernels.hip", ["POLAR_ED_TU=1"], ".ed", []),
            ("polar_kernels.hip", ["POLAR_ED_TU=2"], ".ed32", FLAGS_LIST32),
            ("polar_kernels_sc.hip", [], "", []), ("polar_kernels_p1.hip", [], "", []), ("polar_channel.hip", [], "", []),
-           ("polar_construct.hip", [], "", []), ("polar_host.cpp", [], "", [])]
+           ("polar_construct.hip", [], "", [])] + \
+          [(f, [], "", []) for f in ("polar_handle.cpp", "polar_decode.cpp", "polar_hostpipe.cpp", "polar_montecarlo.cpp", "polar_multi.cpp",
+                                     "polar_debug.cpp")]
+# the test build (libpolar_amd_test.so): the same objects, except that these two are compiled again with -DPOLAR_TEST_HOOKS —
+# the fault-injection keys of include/polar_amd_debug.h exist only there
+TEST_HOOK_SOURCES = ("polar_montecarlo.cpp", "polar_debug.cpp")
+LIB_TEST = os.path.join(HERE, "libpolar_amd_test.so")
 # what POLAR_DEFS may name: instrumentation (measures, does not decode), trimmed development builds (fewer instantiations),
 # and the few A/B switches still open (same bits either way)
 KNOWN_DEFS = {"POLAR_MARGIN", "POLAR_SLOTHIST", "SCLAT_PROF", "POLAR_DEV_GS32", "POLAR_DEV_ONE", "POLAR_NO_FIXED_N",
@@ -124,16 +130,18 @@ def _deps(obj, fallback):
     return out
 
 
-def build(force=False, verbose=False, profile=False, bless=False):
+def build(force=False, verbose=False, profile=False, bless=False, test_hooks=False):
     """profile=True builds the instrumented variant libpolar_amd_prof.so (-DPOLAR_PROFILE: per-phase
-    cycle counters, tools/phase_profile.py); never used by the product path."""
+    cycle counters, tools/phase_profile.py); never used by the product path.
+    test_hooks=True builds libpolar_amd_test.so: the product's objects, except TEST_HOOK_SOURCES compiled with
+    -DPOLAR_TEST_HOOKS (the fault-injection keys of include/polar_amd_debug.h) — what the tests of the failure protocol load."""
     global LIB
     os.makedirs(BUILD, exist_ok=True)
-    lib_out = os.path.join(HERE, "libpolar_amd_prof.so") if profile else LIB
+    lib_out = os.path.join(HERE, "libpolar_amd_prof.so") if profile else (LIB_TEST if test_hooks else LIB)
     tag = ".prof" if profile else ""
     if os.environ.get("POLAR_BUILD_TAG"):          # A/B experiments: separate objects and library
         tag = "." + os.environ["POLAR_BUILD_TAG"]
-        lib_out = os.path.join(HERE, "libpolar_amd_%s.so" % os.environ["POLAR_BUILD_TAG"])
+        lib_out = os.path.join(HERE, "libpolar_amd_%s%s.so" % (os.environ["POLAR_BUILD_TAG"], "_test" if test_hooks else ""))
     # Extra -D macros (POLAR_DEFS) select instrumented or trimmed builds — some of them measure instead of decoding (POLAR_MARGIN
     # overwrites decoded bits with its statistics). They never get the product's library name: a tag is required, every name must be
     # one this tree knows (a typo would otherwise build an ordinary library under an experiment's name, or the reverse), and
@@ -153,6 +161,8 @@ def build(force=False, verbose=False, profile=False, bless=False):
     jobs = []
     for s, defs, otag, xflags in SOURCES:
         src = os.path.join(CSRC, s)
+        if test_hooks and s in TEST_HOOK_SOURCES:
+            defs, otag = defs + ["POLAR_TEST_HOOKS"], otag + ".th"
         obj = os.path.join(BUILD, s + otag + tag + ".o")
         objs.append(obj)
         cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
@@ -197,18 +207,26 @@ def build(force=False, verbose=False, profile=False, bless=False):
         have_link = link_fp
     if force or jobs or have_link != link_fp:
         tl = _torch_lib()
-        cmd = [_hipcc(), "-shared", "-fPIC", "-o", lib_out] + objs
+        # only the C entry points of include/polar_amd*.h leave the library (kernel launchers and internals stay local)
+        vs = os.path.join(BUILD, "exports.map")
+        open(vs, "w").write("{ global: polar_*; local: *; };\n")
+        cmd = [_hipcc(), "-shared", "-fPIC", "-Wl,--version-script=" + vs, "-o", lib_out] + objs
         if tl:
             # hipcc would add -L/opt/rocm/lib -lamdhip64 itself; link by hand instead so the
             # DT_NEEDED entry is the un-versioned name torch's copy is loaded under
             clang = "/opt/rocm/lib/llvm/bin/clang++"
-            cmd = [clang, "-shared", "-fPIC", "-o", lib_out] + objs + \
+            cmd = [clang, "-shared", "-fPIC", "-Wl,--version-script=" + vs, "-o", lib_out] + objs + \
                   ["-L" + tl, "-lamdhip64", "-Wl,-rpath," + tl, "-Wl,-rpath,/opt/rocm/lib", "-lstdc++", "-lm"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         open(link_stamp, "w").write(link_fp)
     return lib_out
+
+
+def build_test(force=False):
+    """libpolar_amd_test.so (see build)."""
+    return build(force=force, test_hooks=True)
 
 
 def build_cli(force=False):

@@ -72,13 +72,14 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         return;
     }
     if (c == "mc_construction") {
-        // counts = polar_mex('mc_construction', n, constellation_id, design_snr_db, seed, num_runs)  (PolarCode.m:143-196)
+        // counts = polar_mex('mc_construction', n, constellation_id, design_snr_db, seed, num_runs [, trial0])  (PolarCode.m:143-196)
+        // trial0 (default 0): first trial of the range — disjoint ranges (parallel workers, several GPUs) are summed by the caller
         need(nrhs, 6, "'mc_construction', n, constellation_id, design_snr_db, seed, num_runs");
         const int n_ = (int)mxGetScalar(prhs[1]);
         if (n_ < 1 || n_ > POLAR_MAX_N_LOG2) mexErrMsgIdAndTxt("polar_amd:size", "bad n");
         std::vector<uint64_t> cnt((size_t)1 << n_, 0);
-        check(polar_mc_construction(n_, (int)mxGetScalar(prhs[2]), mxGetScalar(prhs[3]), (uint64_t)mxGetScalar(prhs[4]), 0,
-                                    (long)mxGetScalar(prhs[5]), 0, cnt.data()));
+        check(polar_mc_construction(n_, (int)mxGetScalar(prhs[2]), mxGetScalar(prhs[3]), (uint64_t)mxGetScalar(prhs[4]),
+                                    nrhs > 6 ? (uint64_t)mxGetScalar(prhs[6]) : 0, (long)mxGetScalar(prhs[5]), 0, cnt.data()));
         plhs[0] = mxCreateDoubleMatrix((mwSize)cnt.size(), 1, mxREAL);
         for (size_t i = 0; i < cnt.size(); ++i) mxGetPr(plhs[0])[i] = (double)cnt[i];
         return;

@@ -6,7 +6,7 @@ counter — is independent of the world size. The only communication is one all-
 of the 2*n_L*n_e error/run counters per round (RCCL over xGMI when the backend is "nccl"); the
 early stop `num_err > max_err` (PolarCode.cpp:725) is evaluated on the reduced counters between
 rounds of `global_batch` trials (default: the native driver's geometric rounds, up to 262144 trials
-PER RANK and round — polar_host.cpp next_round(); the two drivers then take the same rounds and
+PER RANK and round — polar_montecarlo.cpp next_round(); the two drivers then take the same rounds and
 return the same counters).
 """
 import numpy as np
@@ -26,7 +26,7 @@ def _world():
 
 
 def next_round(batch, max_err, done, max_runs, world):
-    """Trials of the next round over all ranks: polar_host.cpp next_round() (fixed `batch`, or geometric: first
+    """Trials of the next round over all ranks: polar_montecarlo.cpp next_round() (fixed `batch`, or geometric: first
     max(256, 2 max_err) rounded up to a multiple of the world size, then as many as all rounds before, at most 262144
     per rank)."""
     if batch:
@@ -84,7 +84,7 @@ def get_bler_quick_ranks(code, ebno_vec, list_size_vec, max_runs=1000, max_err=1
                          stats=None, constellation=None):
     """The same sweep through the library's own driver (polar_get_bler_quick_rank): one process per GPU, this rank's device
     simulates the trials rank, rank + world, ... of every round, the rounds are PIPELINED on the device (a step decodes point 1
-    of the newest round together with the later points of the rounds before it — polar_host.cpp mc_step_launch) and the
+    of the newest round together with the later points of the rounds before it — polar_montecarlo.cpp mc_step_launch) and the
     counters are summed by one all-reduce per step. Same counters as get_bler_quick_sharded and as one GPU alone.
     Returns (bler, err, run)."""
     rank, world = _world()

@@ -25,3 +25,15 @@ def oracle_built():
     import oracle_lib
     oracle_lib.build_oracle()
     return True
+
+
+@pytest.fixture(scope="module")
+def hooks_lib(built_lib):
+    """The TEST build of the library (libpolar_amd_test.so: the product's objects with the fault-injection hooks of
+    include/polar_amd_debug.h compiled in) for the module that asks for it; the product library again afterwards."""
+    import polar_amd
+    from polar_amd import build
+    path = build.build_test()
+    polar_amd.use_library(path)
+    yield path
+    polar_amd.use_library(None)

@@ -101,12 +101,15 @@ class Mex:
         return np.frombuffer(buf, dt).reshape((m, n), order="F").copy()
 
     def __call__(self, cmd, *args, nlhs=1):
+        import time
         prhs = [self._to_mx(cmd)] + [self._to_mx(a) for a in args]
         arr = (C.c_void_p * len(prhs))(*prhs)
         out = (C.c_void_p * max(nlhs, 1))()
         eid, emsg = C.create_string_buffer(256), C.create_string_buffer(1024)
         try:
+            t0 = time.perf_counter()
             rc = self.L.fm_call(nlhs, out, len(prhs), arr, eid, emsg, 1024)
+            self.last_call_seconds = time.perf_counter() - t0      # inside mexFunction: what the MATLAB caller waits for
             if rc:
                 raise MexError(eid.value.decode(), emsg.value.decode())
             res = []

@@ -18,14 +18,56 @@ def _have_gpu():
     return torch.cuda.is_available()
 
 
-def test_exports_every_declared_symbol(built_lib):
-    hdr = open(os.path.join(ROOT, "include", "polar_amd.h")).read()
+def _declared(header):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = sorted(set(re.findall(r"\b(polar_[a-z0-9_]+)\s*\(", hdr)))
-    assert len(names) >= 25
-    lib = C.CDLL(built_lib)
-    missing = [n for n in names if not hasattr(lib, n)]
-    assert not missing, missing
+    return sorted(set(re.findall(r"\b(polar_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_exports_every_declared_symbol(built_lib):
+    """Both libraries (the product and the test build) export every entry point of include/polar_amd.h and of
+    include/polar_amd_debug.h, and nothing but `polar_*` C symbols (kernel launchers and internals stay local)."""
+    import subprocess
+    from polar_amd import build
+    api, dbg = _declared("polar_amd.h"), _declared("polar_amd_debug.h")
+    assert len(api) >= 25 and "polar_debug_set" in dbg and not [n for n in api if n.startswith("polar_debug")]
+    assert "polar_amd_debug.h" not in re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "polar_amd.h")).read(), flags=re.S)
+    for path in (built_lib, build.build_test()):
+        lib = C.CDLL(path)
+        missing = [n for n in api + dbg if not hasattr(lib, n)]
+        assert not missing, (path, missing)
+        exported = [l.split()[-1] for l in subprocess.check_output(["nm", "-D", "--defined-only", path], text=True).splitlines() if " T " in l]
+        foreign = [n for n in exported if not n.startswith("polar_")]
+        assert not foreign, (path, foreign[:5])
+
+
+def test_fault_injection_exists_only_in_the_test_build(built_lib):
+    """The product library has no key that makes a sweep fail, stall or share a device (include/polar_amd_debug.h): polar_debug_set
+    rejects them as unknown; the test build (-DPOLAR_TEST_HOOKS) accepts them. The measurement knobs exist in both."""
+    import polar_amd
+    from polar_amd import build
+    hooks = ("share_device", "fail_device", "fail_collective", "force_workers", "stall_device", "stall_ms")
+    knobs = ("mode_override", "lat_max_b", "host_lanes", "host_prefault", "no_rccl", "multi_timeout_s")
+    g = polar_amd.PolarCode(5, 16, 0.32, 0)
+    assert g.debug_get("test_hooks") == 0
+    for k in hooks:
+        with pytest.raises(polar_amd.PolarError, match="unknown key"):
+            g.debug_set(k, 1)
+    for k in knobs:
+        g.debug_set(k, 0)
+    try:
+        polar_amd.use_library(build.build_test())
+        t = polar_amd.PolarCode(5, 16, 0.32, 0)
+        assert t.debug_get("test_hooks") == 1
+        for k in hooks + knobs:
+            t.debug_set(k, 0)
+        t.close()
+    finally:
+        polar_amd.use_library(None)
+    src = open(os.path.join(ROOT, "polar_amd", "csrc", "polar_debug.cpp")).read()
+    for k in hooks:          # every fault-injection key sits inside a POLAR_TEST_HOOKS block
+        i = src.index('"%s"' % k)
+        assert src.rfind("#ifdef POLAR_TEST_HOOKS", 0, i) > src.rfind("#endif", 0, i), k
 
 
 def test_no_oracle_or_torch_types_in_abi():
@@ -137,10 +179,10 @@ def test_weak_unfrozen_leaves_are_classified_at_creation(built_lib):
     weak, on its own channel it is not — the device guard looks at the VALUE before it acts)."""
     import polar_amd
     L = polar_amd.lib()
-    L.polar_debug_weak_leaves.restype = C.c_int
-    L.polar_debug_weak_leaves.argtypes = [C.c_void_p]
+    L.polar_get_weak_leaves.restype = C.c_int
+    L.polar_get_weak_leaves.argtypes = [C.c_void_p]
     def weak(g):
-        return L.polar_debug_weak_leaves(g._h)
+        return L.polar_get_weak_leaves(g._h)
     for (n, K, eps, crc) in [(11, 1024, 0.32, 16), (11, 1024, 0.32, 0), (9, 256, 0.32, 0), (10, 512, 0.32, 0), (10, 614, 0.5, 0), (4, 10, 0.32, 0)]:
         assert weak(polar_amd.PolarCode(n, K, eps, crc)) == 0, (n, K, eps, crc)
     assert weak(polar_amd.PolarCode(9, 505, 0.7, 0)) > 100
@@ -163,8 +205,8 @@ def test_explicit_tables_with_weak_leaves_return_a_status_not_an_error(built_lib
                                  od.ctypes.data_as(C.POINTER(C.c_uint16)), None, C.byref(h))
     assert rc == polar_amd.POLAR_W_WEAK_LEAVES == 1 and h.value
     assert b"unfrozen leaves" in L.polar_last_error()
-    L.polar_debug_weak_leaves.restype = C.c_int
-    assert L.polar_debug_weak_leaves(h) == src.weak_leaves > 100
+    L.polar_get_weak_leaves.restype = C.c_int
+    assert L.polar_get_weak_leaves(h) == L.polar_debug_weak_leaves(h) == src.weak_leaves > 100
     L.polar_destroy(h)
     with pytest.warns(polar_amd.PolarWeakLeavesWarning):
         g = polar_amd.PolarCode.from_tables(9, 505, 0, fr, od)
@@ -196,9 +238,10 @@ def test_environment_knobs_are_read_once_and_validated(built_lib, monkeypatch):
         g2.debug_set("mode_override", 3)
     with pytest.raises(polar_amd.PolarError, match="unknown key"):
         g2.debug_set("no_such_knob", 1)
-    for k in ("share_device", "fail_device", "fail_collective", "force_rccl", "no_rccl", "sc_no_fold", "no_tables"):
+    for k in ("force_rccl", "no_rccl", "sc_no_fold", "no_tables"):
         g2.debug_set(k, 1)
-    src = open(os.path.join(ROOT, "polar_amd", "csrc", "polar_host.cpp")).read()
+    csrc = os.path.join(ROOT, "polar_amd", "csrc")
+    src = "".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)) if f.endswith((".cpp", ".h", ".hip")))
     body = src[src.index("int read_env_knobs("):]
     body = body[:body.index("\n}\n")]
     assert src.count("getenv(") == body.count("getenv(") > 0      # every getenv of the library sits in read_env_knobs

@@ -67,7 +67,7 @@ def test_sharded_counters_equal_unsharded(oracle_built, tmp_path):
 
 
 def test_automatic_rounds_follow_the_native_driver():
-    """polar_amd/montecarlo.py takes the rounds of polar_host.cpp next_round(): `batch` trials over all ranks, or geometric —
+    """polar_amd/montecarlo.py takes the rounds of polar_montecarlo.cpp next_round(): `batch` trials over all ranks, or geometric —
     max(256, 2 max_err) first (rounded up to a multiple of the world size), then as many as all rounds before, at most 262144 PER
     RANK (round 3 capped the round over all ranks: eight GPUs got 32768 trials each)."""
     from polar_amd.montecarlo import next_round

@@ -89,7 +89,7 @@ def test_ragged_batches_and_empty(built_lib, oracle_built):
 
 @pytest.mark.parametrize("L", [1, 2, 4, 32])
 def test_pipelined_host_batches_at_chunk_boundaries(built_lib, oracle_built, L):
-    """Large host-pointer batches are cut into chunks (pinned staging, copy stream, several decode lanes: polar_host.cpp
+    """Large host-pointer batches are cut into chunks (pinned staging, copy stream, several decode lanes: polar_hostpipe.cpp
     host_decode_pipelined). Forced here on small batches with tiny chunks: a batch that is one codeword short of / exactly /
     one codeword over a whole number of chunks, fewer chunks than ring slots and many more, one / two / five lanes, doubles and
     floats — every row must be what the unpipelined path returns (== the oracle), in its place."""

@@ -264,11 +264,12 @@ def test_gateway_monte_carlo_design(mex, tmp_path):
     explicit-table handle): counts == the numpy fixture / the library's own entry point; a second call reads the file."""
     import fake_matlab
     import polar_amd
-    n, cid, seed, trial0, runs = (int(x) for x in FX["mc/6_1/params"])
-    assert trial0 == 0
-    snr = float(FX["mc/6_1/snr"][0])
-    cnt = mex('mc_construction', float(n), float(cid), snr, float(seed), float(runs))
-    assert cnt.shape == (64, 1) and (cnt[:, 0].astype(np.int64) == FX["mc/6_1/counts"]).all()
+    for key in ("6_4", "6_1", "7_3"):                # (BPSK from trial 0 with the default; 4-ASK and 16-ASK from a later first trial)
+        n, cid, seed, trial0, runs = (int(x) for x in FX[f"mc/{key}/params"])
+        snr = float(FX[f"mc/{key}/snr"][0])
+        args = [float(n), float(cid), snr, float(seed), float(runs)] + ([float(trial0)] if trial0 else [])
+        cnt = mex('mc_construction', *args)
+        assert cnt.shape == (1 << n, 1) and cnt.dtype == np.float64 and (cnt[:, 0].astype(np.int64) == FX[f"mc/{key}/counts"]).all(), key
     libc.srand(1)
     pc = fake_matlab.PolarCodeM(1024, 512, 0.32, 0)
     est, path = pc.monte_carlo_code_construction(13, 2000, 'ask16-gray', 'bicm', 9, data_dir=str(tmp_path))
