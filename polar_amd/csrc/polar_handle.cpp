@@ -200,9 +200,9 @@ int derive_tables(polar_code *h) {
 }
 
 int ensure_device(polar_code *h, DevGuard &dg) {
-    // (every compute entry point passes here: a handle whose multi-device round never returned may share its scratch and
-    // streams with the worker that is stuck — it computes nothing any more)
-    if (h->multi_poisoned) return fail(POLAR_E_DEVICE, "an earlier multi-device round of this handle never returned: the handle accepts no further calls (create a new one)");
+    // (every compute entry point passes here: when the worker of a multi-device round that never returned was working on this
+    // very context — the handle itself is device 0 of its list — its scratch and tables may still be in that worker's hands)
+    if (h->ctx_stuck) return fail(POLAR_E_DEVICE, "an earlier multi-device round of this handle never returned: the handle accepts no further calls (create a new one)");
     int cur = -1;
     if (hipGetDevice(&cur) == hipSuccess && h->device >= 0 && cur != h->device) dg.prev = cur;
     if (h->dev_ready) {

@@ -296,6 +296,7 @@ struct polar_code {
     // (an 8-rank ncclCommInitAll costs about as long as a short sweep runs)
     struct MultiCtx *multi = nullptr;
     bool multi_poisoned = false;     // a multi-device round never returned (MultiCtx::run_all step 3): no further multi-device calls
+    bool ctx_stuck = false;          //   ... and the worker that never came back was working on THIS context: it computes nothing any more
     // zero-copy staging of the host-pointer entry points for the smallest batches (host_decode): pinned, device-mapped
     void *pin_in = nullptr, *pin_in_dev = nullptr;     // LLR rows
     uint8_t *pin_out = nullptr, *pin_out_dev = nullptr; // decoded bits [B][K] followed by one flag byte per codeword

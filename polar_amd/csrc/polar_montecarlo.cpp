@@ -516,6 +516,8 @@ int bler_impl(polar_code_t *h, int constellation, const int *devices, int n_dev,
             err_msg = "a multi-device round exceeded the watchdog (" + std::to_string(h->knobs.multi_timeout_s) + " s): communicators aborted" +
                       (mc->stuck ? "; a worker never returned, the handle accepts no further get_bler_quick calls" : "");
         }
+        if (mc->stuck)                               // which contexts the workers that never came back are working on
+            for (int d = 0; d < n_dev; ++d) if (mc->busy && mc->busy[d]) ctx[d]->ctx_stuck = true;
         // (a stuck worker may still write the job's vectors: they are not read then)
         // report the device that failed first-hand, not a peer that was merely told to stop
         for (int pass = 0; pass < 2 && !rc_all && !mc->stuck; ++pass)

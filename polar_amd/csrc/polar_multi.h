@@ -101,9 +101,12 @@ struct MultiCtx {
     bool quit = false, timed_out = false, stuck = false;
     std::atomic<bool> abort_req{false};
     std::unique_ptr<HostBarrier> bar;
+    std::unique_ptr<std::atomic<char>[]> busy;       // busy[d]: worker d is inside a job (who is stuck when a round is given up)
 
     void start_workers(int n, bool force_threads) {
         bar.reset(new HostBarrier(n));
+        busy.reset(new std::atomic<char>[n]);
+        for (int d = 0; d < n; ++d) busy[d] = 0;
         if (n <= 1 && !force_threads) return;        // a single device runs on the calling thread (no watchdog then)
         for (int d = 0; d < n; ++d)
             threads.emplace_back([this, d] {
@@ -117,7 +120,9 @@ struct MultiCtx {
                         seen = gen;
                         f = job;
                     }
+                    busy[d] = 1;
                     f(d);
+                    busy[d] = 0;
                     {
                         std::lock_guard<std::mutex> lk(m);
                         if (--pending == 0) cv_done.notify_all();

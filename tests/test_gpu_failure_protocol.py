@@ -152,9 +152,22 @@ def test_a_worker_that_never_answers_costs_the_handle_not_the_caller(built_lib):
     with pytest.raises(polar_amd.PolarError, match="never returned"):
         g.get_bler_quick([1.0], [1], **args)
     llr, _ = o.synth_llr(5, 0, 16, o.snr_sqrt_linear(2.0))
+    assert (g.decode_scl_llr(llr, 4) == o.decode_scl_llr(llr, 4)).all()     # (the stuck worker had a per-device copy, not the handle)
+    g.debug_set("lat_max_b", -1)                                            # setters leave the leaked per-device contexts alone
     assert (g.decode_scl_llr(llr, 4) == o.decode_scl_llr(llr, 4)).all()
-    time.sleep(4.0)              # (let the sleeper finish its round on the leaked context before the process goes on)
-    g.close()
+    # the same with the worker that works on the HANDLE'S OWN context (device 0 of the list) stuck: the handle computes nothing
+    # any more — its scratch may still be in that worker's hands (round-5 advisor)
+    _, g2 = _pair(8, 128, 8)
+    g2.debug_set("share_device", 1)
+    g2.get_bler_quick([1.0], [1, 4], devices=[0, 0], **args)
+    g2.debug_set("multi_timeout_s", 1); g2.debug_set("multi_grace_s", 1)
+    g2.debug_set("stall_device", 0); g2.debug_set("stall_ms", 6000)
+    with pytest.raises(polar_amd.PolarError, match="never returned"):
+        g2.get_bler_quick([1.0], [1, 4], devices=[0, 0], **args)
+    with pytest.raises(polar_amd.PolarError, match="accepts no further calls"):
+        g2.decode_scl_llr(llr, 4)
+    time.sleep(5.0)              # (let the sleepers finish their rounds on the leaked contexts before the process goes on)
+    g.close(); g2.close()
 
 
 def test_worker_threads_live_on_the_handle_between_calls(built_lib):
