@@ -156,7 +156,7 @@ def build(force=False, verbose=False, profile=False, bless=False, test_hooks=Fal
             raise SystemExit("polar_amd.build: POLAR_DEFS=%r without POLAR_BUILD_TAG: development builds never take the product "
                              "library's name (libpolar_amd.so)" % os.environ["POLAR_DEFS"])
     headers = [os.path.join(INC, f) for f in os.listdir(INC)] + \
-              [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+              [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     objs = []
     jobs = []
     for s, defs, otag, xflags in SOURCES:

@@ -43,158 +43,7 @@
 #define PROF_OUT
 #endif
 
-namespace {
-
-// ---- fp64 transcendentals for the f-node and the path metric --------------------------------
-// The reference evaluates log((e^(a+b)+1)/(e^a+e^b)) and log(1+e^x) with libm. Bit-identity with
-// glibc's exp/log is not reachable on a GPU (ocml differs in the last ulp as well); what parity
-// needs is that every DECISION (sign of a leaf LLR, order of path metrics) is the reference's,
-// i.e. an absolute accuracy far below any decision margin. These routines keep ~1e-16 absolute
-// accuracy (the rounding level of the reference's own 1+e^x) at ~1/3 of the instruction count
-// of the libm-style sequence, using two small LDS tables (no division):
-//   exp(-x) = T[k&63] * 2^(k>>6) * p5(s),  -x = k*ln2/64 + s  (k <= 0, T[f] = 2^(f/64))
-//   log(m)  = LC[j] + log1p((m - c_j)/c_j),   c_j = 1 + j/128 = m rounded to 7 mantissa bits
-// and the identity  f(a,b) = sgn(a)sgn(b)min(|a|,|b|) + h(|a+b|) - h(|a-b|),  h(x) = log1p(e^-x).
-// Structural exactness is preserved: h(x) == 0 exactly for x >= 36.74 (where the reference's
-// 1+e^-x rounds to 1), f(0,b) == 0 exactly, f is symmetric, log(1+e^x) -> +inf for x > 709.78.
-__device__ __forceinline__ double h_fn(double x, const Tabs &tb) {       // log1p(e^-x), x >= 0
-    return log_1p2(1.0 + exp_neg(x, tb), tb);
-}
-// h(x) - h(y): the two evaluations of an f-node written in lockstep, so that their table reads are
-// issued together (2 LDS round trips per f-node instead of 4) and the two dependent fp64 chains
-// overlap. Same operations and rounding as h_fn(x) - h_fn(y).
-__device__ __forceinline__ double h_diff(double x, double y, const Tabs &tb) {
-    const double kx = __builtin_rint(x * -92.332482616893657), ky = __builtin_rint(y * -92.332482616893657);
-    const int ix = (int)kx, iy = (int)ky;
-    const double tx = tb.T[ix & 63], ty = tb.T[iy & 63];
-    double sx = __builtin_fma(kx, -0.010830424696223417, -x), sy = __builtin_fma(ky, -0.010830424696223417, -y);
-    sx = __builtin_fma(kx, -2.5728046223276688e-14, sx); sy = __builtin_fma(ky, -2.5728046223276688e-14, sy);
-    double px = sx * (1.0 / 120.0) + 1.0 / 24.0, py = sy * (1.0 / 120.0) + 1.0 / 24.0;
-    px = __builtin_fma(px, sx, 1.0 / 6.0); py = __builtin_fma(py, sy, 1.0 / 6.0);
-    px = __builtin_fma(px, sx, 0.5); py = __builtin_fma(py, sy, 0.5);
-    px = __builtin_fma(px, sx, 1.0); py = __builtin_fma(py, sy, 1.0);
-    px = __builtin_fma(px, sx, 1.0); py = __builtin_fma(py, sy, 1.0);
-    const double mx = 1.0 + __builtin_ldexp(tx * px, ix >> 6), my = 1.0 + __builtin_ldexp(ty * py, iy >> 6);
-    double cx, cy;
-    const int nx = log_slot(mx, cx), ny = log_slot(my, cy);
-    const double rcx = tb.RC[nx], rcy = tb.RC[ny], lcx = tb.LC[nx], lcy = tb.LC[ny];
-    const double qx = (mx - cx) * rcx, qy = (my - cy) * rcy;
-    double ux = qx * (-1.0 / 6.0) + 0.2, uy = qy * (-1.0 / 6.0) + 0.2;
-    ux = __builtin_fma(ux, qx, -0.25); uy = __builtin_fma(uy, qy, -0.25);
-    ux = __builtin_fma(ux, qx, 1.0 / 3.0); uy = __builtin_fma(uy, qy, 1.0 / 3.0);
-    ux = __builtin_fma(ux, qx, -0.5); uy = __builtin_fma(uy, qy, -0.5);
-    ux = __builtin_fma(ux, qx, 1.0); uy = __builtin_fma(uy, qy, 1.0);
-    return __builtin_fma(qx, ux, lcx) - __builtin_fma(qy, uy, lcy);
-}
-__device__ __attribute__((noinline)) double f_literal(double a, double b) {
-    return log((exp(a + b) + 1) / (exp(a) + exp(b)));
-}
-__device__ __attribute__((noinline)) double softplus_literal(double x) { return log(1 + exp(x)); }
-// f-node (check node), exact + min-sum branches: PolarCode.cpp:437-446
-__device__ __forceinline__ double f_node(double a, double b, const Tabs &tb) {
-    const double fa = fabs(a), fb = fabs(b);
-    const double mx = __builtin_fmax(fa, fb);      // (v_max_f64 / v_min_f64 with |.| source modifiers)
-    const double mn = __builtin_fmin(fa, fb);
-    // sgn(a)*sgn(b)*min(|a|,|b|) (PolarCode.cpp:443-445, sgn(0) = 0): the magnitude with the XOR of the
-    // two sign bits, done on the high word instead of int->double conversions and multiplies; it is
-    // also the leading term of the exact expression below
-    const int sx = (__double2hiint(a) ^ __double2hiint(b)) & (int)0x80000000;
-    const double ms = __hiloint2double(__double2hiint(mn) | sx, __double2loint(mn));
-    if (40 > mx) {
-        // |f| <= min(|a|,|b|): when that is within a few orders of the rounding noise (1e-16) the
-        // reference's result IS its rounding noise (e.g. exactly 0 once e^a, e^b round to 1), so the
-        // literal expression is evaluated for those (physically never occurring) elements.
-        if (POLAR_UNLIKELY2(mn < 9.5367431640625e-07)) return f_literal(a, b);
-        return ms + h_diff(fabs(a + b), fabs(a - b), tb);
-    }
-    return (mn == 0.0) ? 0.0 : ms;     // min-sum branch
-}
-// Two f-nodes at once: same results as f_node() twice, but ONE wave-uniform branch around the two exact
-// evaluations, so that their four h() chains sit in one basic block and overlap (a per-node divergent
-// branch serialises the nodes). Used where the nodes are otherwise strictly serial (rate-0 blocks); in
-// the unrolled layer loops it was measured slower (register pressure: -1.4 % fused loop, -25 % LDS visits). Lanes that do not need the exact value compute it on whatever they
-// hold (finite garbage at worst: the table index is masked) and discard it.
-__device__ __forceinline__ void f_node2(double a0, double b0, double a1, double b1, const Tabs &tb, double &r0, double &r1) {
-    const double fa0 = fabs(a0), fb0 = fabs(b0), fa1 = fabs(a1), fb1 = fabs(b1);
-    const double mx0 = __builtin_fmax(fa0, fb0), mn0 = __builtin_fmin(fa0, fb0);
-    const double mx1 = __builtin_fmax(fa1, fb1), mn1 = __builtin_fmin(fa1, fb1);
-    const int s0 = (__double2hiint(a0) ^ __double2hiint(b0)) & (int)0x80000000;
-    const int s1 = (__double2hiint(a1) ^ __double2hiint(b1)) & (int)0x80000000;
-    const double m0 = __hiloint2double(__double2hiint(mn0) | s0, __double2loint(mn0));     // sgn*sgn*min (min-sum value)
-    const double m1 = __hiloint2double(__double2hiint(mn1) | s1, __double2loint(mn1));
-    r0 = (mn0 == 0.0) ? 0.0 : m0;
-    r1 = (mn1 == 0.0) ? 0.0 : m1;
-    const bool e0 = 40 > mx0, e1 = 40 > mx1;
-    if (wave_any(e0 || e1)) {
-        const double x0 = m0 + h_diff(fabs(a0 + b0), fabs(a0 - b0), tb);
-        const double x1 = m1 + h_diff(fabs(a1 + b1), fabs(a1 - b1), tb);
-        const bool t0 = e0 && mn0 < 9.5367431640625e-07, t1 = e1 && mn1 < 9.5367431640625e-07;
-        if (e0) r0 = x0;
-        if (e1) r1 = x1;
-        if (POLAR_UNLIKELY2(wave_any(t0 || t1))) {                    // noise regime (see f_node)
-            if (t0) r0 = f_literal(a0, b0);
-            if (t1) r1 = f_literal(a1, b1);
-        }
-    }
-}
-// g-node: PolarCode.cpp:449-450  (1 - 2u)*a + b
-__device__ __forceinline__ double g_node(double a, double b, unsigned u) {
-    // (1 - 2u) is +1 or -1 and the product with it is exact: flip the sign bit of a, then add
-    const double sa = __hiloint2double(__double2hiint(a) ^ (int)(u << 31), __double2loint(a));
-    return sa + b;
-}
-// The path-metric terms log(1 + exp(-+llr)) of PolarCode.cpp:483,505-506 for a = |llr| >= 0, with ONE
-// h evaluation: log(1+e^-a) = h(a) (exactly 0 for a >= 36.74, where the reference's 1+e^-a rounds to
-// 1), log(1+e^a) = a + h(a) (+inf beyond the fp64 exp overflow point 709.78, as the reference).
-// `skip` (wave-uniform: every lane has a >= 37) avoids the transcendental altogether.
-__device__ __forceinline__ void softplus_pair(double a, bool skip, const Tabs &tb, double &sneg, double &spos) {
-    double hx = 0.0;
-    if (!skip) {
-        if (POLAR_UNLIKELY2(a < 9.5367431640625e-07)) {            // noise regime: literal expressions (see f_node)
-            sneg = softplus_literal(-a);
-            spos = softplus_literal(a);
-            return;
-        }
-        // per-lane saturation: 1 + e^-a rounds to 1 for a >= 37, and an infinite (or > 1e78) leaf LLR must not
-        // reach the range reduction of exp_neg (inf * c - inf = NaN would poison the metric)
-        hx = (a >= 37.0) ? 0.0 : h_fn(__builtin_fmin(a, 37.0), tb);
-    }
-    sneg = hx;
-    spos = (a > 709.782712893384) ? __builtin_inf() : a + hx;
-}
-
-
-// leaf terms for the path metric. LLR-domain kernel: `leaf` is the LLR; E-domain: stored form.
-//   neg  = (llr < 0);  al = |llr|;  sneg = log(1+e^-|llr|);  spos = log(1+e^|llr|)
-// actw: the wave mask of `active` (kept by the caller: a ballot of a compound bool costs a round trip through a VGPR)
-template <bool ED>
-__device__ __forceinline__ void leaf_terms(double leaf, bool active, u64 actw, const Tabs &tb, bool &neg, double &al, double &sneg, double &spos) {
-    if (!ED) {
-        al = fabs(leaf);
-        neg = leaf < 0;
-        const bool skip = wave_all(!active || al >= 37.0);
-        sneg = 0.0; spos = 0.0;
-        if (active) softplus_pair(al, skip, tb, sneg, spos);
-    } else {
-        const double m = fabs(leaf);
-        const bool isl = m > 1.0;
-        neg = (__double2hiint(leaf) < 0) && m != 1.0;
-        al = m;
-        const u64 m_e = actw & __builtin_amdgcn_fcmp(m, 1.0, 13);           // ULE: active lanes holding an E-form value
-        if (POLAR_LIKELY2(m_e != 0)) {
-            const double l = -ed_log(__builtin_fmin(__builtin_fmax(m, ED_EMIN), 1.0), tb);
-            if (!isl) al = l;
-        }
-        const double onep = 1.0 + m;                 // == 1 exactly from E <= 2^-53 on, as the reference's 1 + e^-|x|
-        sneg = 0.0;
-        if (POLAR_LIKELY2((m_e & __builtin_amdgcn_fcmp(onep, 1.0, 14)) != 0)) {      // UNE
-            const double h = log_1p2(__builtin_fmin(onep, 2.0), tb);
-            if (!isl) sneg = h;
-        }
-        spos = (al > 709.782712893384) ? __builtin_inf() : al + sneg;
-    }
-}
-}  // namespace
+#include "polar_llr_nodes.h"
 
 // Channel LLRs at the boundary are doubles (the reference's type) or floats (polar_decode_scl_llr_batch_dev_f32):
 // a float is widened — exactly — in the load itself, there is no staging copy. ch_row() = row `cw` of p.llr.
@@ -309,6 +158,13 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     // layer 3 gather their inputs from the table. Two of the seven HBM-resident layers disappear.
     const int S1 = N / 2, S2 = N / 4;
     const bool tbl = ED && !PIPE && GS == 32 && N >= 1024 && p.tab_scr != nullptr && p.prefix_q > 0;
+    // ---- layer 1 re-derived (lane groups of 4, 8, 16; exp-domain; round 6): the values of layer 1 a path computes at phi = N/2
+    // (x1[e] = g(ch, ch', u1[e]), N/2 of them) have ONE later reader, the g-visit of layer 2 at phi = 3N/4. They are not stored:
+    // that visit computes them again from the codeword's channel row — 256 contiguous bytes per pass, shared by the paths of the
+    // group, instead of 16 rows per path — and the path's partial sums. 8 KiB written and 8 KiB read per path less, for N/2
+    // g-nodes per path more. (The list of 32 has its value tables instead; smaller groups amortise a table over too few paths.)
+    constexpr bool RD1 = ED && !PIPE && !LAT && GS >= 4 && GS <= 16;
+    const bool rd1 = RD1 && n >= 10 && p.rd1;
     double *tab_w = tbl ? p.tab_scr + (size_t)wave_id * G * (size_t)(3 * N) : nullptr;       // per codeword: X[N/2][2], T2[N/4][8]
     uint32_t *g_v = tbl ? p.var_scr + (size_t)wave_id * (size_t)(S2 / 8) * 64 : nullptr;     // V words [N/32][64]
 
@@ -467,1016 +323,14 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
                 ctl_next = ctlp[nphi < N ? nphi : 0];
             }
             const int lam_stop = n - zb;
-            // ---------------- recursivelyCalcLLR(n, phi): PolarCode.cpp:422-455 ----------------
-            const int lam_top = (phi == phi_start && forced_top) ? forced_top : (phi ? (n - __builtin_ctz((unsigned)phi)) : 1);
-            double leaf = 0.0;
-            for (int lam = lam_top; lam <= lam_stop; ++lam) {
-                if constexpr (LAT) {
-                    // ---- one layer, its elements spread over the 64 / GS lanes of each path (see the template's comment)
-                    LANE_CTX
-                    const int sh_ = n - lam, S_ = 1 << sh_, e_ = lane / GS;
-                    const bool odd_ = (phi >> sh_) & 1;
-                    const int pin_ = (lam > 1) ? pL.get(sh_ + 1) : 0;
-                    const double *srcp = (lam > 1) ? lat_a + (size_t)(2 * S_ - 1) * GS + pin_ : lat_ch;
-                    const int sstr = (lam > 1) ? GS : 1;
-                    double *dstp = lat_a + (size_t)(S_ - 1) * GS + lig;
-                    const uint32_t *cwp_ = (odd_ && S_ > 32) ? g_cl + (size_t)(S_ / 32 - 2) * CST + pC.get(sh_) : nullptr;
-                    auto one = [&](int j, double a_, double b_) -> double {
-                        if (!odd_) return FN(a_, b_);
-                        if (S_ <= 32) return GN(a_, b_, (uint32_t)(clsmall >> S_), j);
-                        return GN(a_, b_, cwp_[(size_t)(j >> 5) * CST], j & 31);
-                    };
-                    if (S_ >= 4 * EL) {
-                        for (int j0 = e_; j0 < S_; j0 += 4 * EL) {
-                            double a_[4], b_[4], r_[4];
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) { a_[k] = srcp[(size_t)(j0 + k * EL) * sstr]; b_[k] = srcp[(size_t)(j0 + k * EL + S_) * sstr]; }
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) r_[k] = one(j0 + k * EL, a_[k], b_[k]);
-                            if (active) {
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) dstp[(size_t)(j0 + k * EL) * GS] = r_[k];
-                            }
-                        }
-                    } else {
-                        for (int j = e_; j < (S_ > EL ? S_ : EL); j += EL) {
-                            const bool in_ = j < S_;
-                            const double a_ = srcp[(size_t)(in_ ? j : 0) * sstr], b_ = srcp[(size_t)((in_ ? j : 0) + S_) * sstr];
-                            const double r_ = one(in_ ? j : 0, a_, b_);
-                            if (active && in_) dstp[(size_t)j * GS] = r_;
-                        }
-                    }
-                    if (active) pL.set(sh_, lig);
-                    wave_mem_fence();
-                    if (S_ == 1) leaf = lat_a[lig];            // (every lane of the path: the element-0 lane wrote it)
-                    PROF(S_ >= EL ? (odd_ ? 1 : 2) : (S_ >= 4 ? 3 : 4))
-                    continue;
-                }
-                if (POLAR_UNLIKELY2(tbl && lam <= 2 && phi >= S2)) {
-                    // phi = N/4, N/2, 3N/4: the visits of layers 1 and 2 are replaced by the table build
-                    const int kind = phi / S2;                      // 1: h (g of the shared layer 1), 2: f, 3: g
-                    LANE_CTX
-                    double *Xc = tab_w + (size_t)(lane / GS) * (size_t)(3 * N), *T2c = Xc + N;
-                    if (valid) {                                    // all lanes of the codeword, whatever their path's state
-                        if (kind == 1) {
-                            const double *x1f = p.pre + cw_of_lane(lane) * (size_t)(N - p.prefix_q + 1) + 1;     // layer 1, first half (prefix kernel)
-                            for (int j = lig; j < S2; j += GS) {
-                                const double a = x1f[j], b = x1f[j + S2];
-                                T2c[8 * j + 0] = g_node_e(a, b, 0u, tb);
-                                T2c[8 * j + 1] = g_node_e(a, b, 0x80000000u, tb);
-                            }
-                        } else {
-                            if (kind == 2) {
-                                const double *chr = ch_row<ED>(p, cw_of_lane(lane), N);
-                                for (int e = lig; e < S1; e += GS) {
-                                    const unsigned i0 = __brev((unsigned)e) >> (32 - n);
-                                    const double a = CH(chr, i0), b = CH(chr, i0 + 1);
-                                    Xc[2 * e + 0] = g_node_e(a, b, 0u, tb);
-                                    Xc[2 * e + 1] = g_node_e(a, b, 0x80000000u, tb);
-                                }
-                                wave_mem_fence();
-                            }
-                            for (int j = lig; j < S2; j += GS) {
-                                const double a0 = Xc[2 * j], a1 = Xc[2 * j + 1], b0 = Xc[2 * (j + S2)], b1 = Xc[2 * (j + S2) + 1];
-                                if (kind == 2) {
-                                    T2c[8 * j + 0] = f_node_e(a0, b0, guard); T2c[8 * j + 1] = f_node_e(a1, b0, guard);
-                                    T2c[8 * j + 2] = f_node_e(a0, b1, guard); T2c[8 * j + 3] = f_node_e(a1, b1, guard);
-                                } else {
-#pragma unroll
-                                    for (int v = 0; v < 8; ++v)
-                                        T2c[8 * j + v] = g_node_e((v & 1) ? a1 : a0, (v & 2) ? b1 : b0, (unsigned)(v >> 2) << 31, tb);
-                                }
-                            }
-                        }
-                    }
-                    // the path's variant nibbles V[e] = u1[e] | u1[e + N/4] << 1 | u2[e] << 2 (kind 1: u2[e] only), 8 per word
-                    // (packing them per consumer pass instead — two words per pass — costs more in the build than the
-                    // visit saves: -5 %)
-                    if (active) {
-                        const uint32_t *c1p = g_cl + (size_t)(S1 / 32 - 2) * 64 + gbase + pC.get(n - 1);
-                        const uint32_t *c2p = g_cl + (size_t)(S2 / 32 - 2) * 64 + gbase + pC.get(n - 2);
-                        auto spread = [](uint32_t x) {               // bit i of the low byte -> bit 4i
-                            uint32_t t = (x | (x << 12)) & 0x000F000Fu;
-                            t = (t | (t << 6)) & 0x03030303u;
-                            return (t | (t << 3)) & 0x11111111u;
-                        };
-                        for (int w32 = 0; w32 < S2 / 32; ++w32) {
-                            const uint32_t ua = (kind >= 2) ? c1p[(size_t)w32 * 64] : 0u, ub = (kind >= 2) ? c1p[(size_t)(w32 + S2 / 32) * 64] : 0u;
-                            const uint32_t uc = (kind != 2) ? c2p[(size_t)w32 * 64] : 0u;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                uint32_t vw;
-                                if (kind == 1) vw = spread((uc >> (8 * q)) & 0xFFu);
-                                else vw = spread((ua >> (8 * q)) & 0xFFu) | (spread((ub >> (8 * q)) & 0xFFu) << 1) | (spread((uc >> (8 * q)) & 0xFFu) << 2);
-                                g_v[(size_t)(4 * w32 + q) * 64 + lane] = vw;
-                            }
-                        }
-                        pC.set(15, lig);                             // slot of this path's V words
-                    }
-                    wave_mem_fence();
-                    lam = 2;
-                    continue;                                        // next: layer 3 with the table as its source
-                }
-                const int sh = n - lam;
-                const int S = 1 << sh;
-                const bool odd = (phi >> sh) & 1;
-                // ---- fused visit of two consecutive layers (lam: size S, op f/g; lam+1: size S/2, always
-                // f right after): the values of layer lam are written (the later g-visit of lam+1 needs
-                // them) but NOT re-read from HBM for the f-visit of lam+1. Only when the source of lam
-                // is HBM-resident (channel LLRs or a scratch layer).
-#ifdef POLAR_SLOTHIST
-                // Measurement build (tools/slot_histogram.py; round-3 verdict item 2): for every visit whose SOURCE layer is
-                // HBM-resident, how many DISTINCT source slots the active paths of a codeword read (pL.get(sh + 1)) — per
-                // visit kind (f / g) and layer size. An f-visit whose source slots coincide would compute and store identical
-                // rows. hist[kind][sh][distinct] += 1, plus sum of active paths and of paths reading their OWN slot.
-                if (GS == 32 && lam > 1 && 2 * S > SL && p.pm_out) {
-                    LANE_CTX
-                    const bool in_pre_ = p.prefix_q > 0 && 2 * S >= p.prefix_q && phi < 2 * S;
-                    const bool tab_ = tbl && lam == 3 && phi >= S2;
-                    if (!in_pre_ && !tab_) {
-                        const int pin_ = pL.get(sh + 1);
-                        int d0 = 0, d1 = 0;
-                        for (int s_ = 0; s_ < 32; ++s_) {
-                            const u64 m_ = __ballot(active && pin_ == s_);
-                            d0 += (m_ & 0xFFFFFFFFull) != 0; d1 += (m_ >> 32) != 0;
-                        }
-                        const u64 own_ = __ballot(active && pin_ == lig);
-                        u64 *hb = reinterpret_cast<u64 *>(p.pm_out) + 64 + (size_t)((odd ? 1 : 0) * 12 + sh) * 40;
-                        if (lane == 0) {
-                            if (actw & 0xFFFFFFFFull) { atomicAdd(hb + d0, 1ull); atomicAdd(hb + 34, (u64)__popcll(actw & 0xFFFFFFFFull)); atomicAdd(hb + 35, (u64)__popcll(own_ & 0xFFFFFFFFull)); }
-                            if (actw >> 32) { atomicAdd(hb + d1, 1ull); atomicAdd(hb + 34, (u64)__popcll(actw >> 32)); atomicAdd(hb + 35, (u64)__popcll(own_ >> 32)); }
-                        }
-                    }
-                }
-#endif
-                if (!PIPE && S >= 8 && 2 * S > SL && lam + 1 <= lam_stop && ((phi >> (sh - 1)) & 1) == 0) {   // (lam+1 is an f-visit)
-                    const int H = S / 2;
-#ifdef POLAR_SADDR
-                    // (not from the prefix buffer, whose rows are per codeword: once per codeword, left to the two-layer body)
-                    const bool deep = (lam + 3 <= lam_stop) && (phi & (S - 1)) == 0 && !(lam > 1 && p.prefix_q > 0 && 2 * S >= p.prefix_q && phi < 2 * S);
-#else
-                    const bool deep = (lam + 3 <= lam_stop) && (phi & (S - 1)) == 0;        // four layers at once (else two)
-#endif
-                    if (active) {
-                        LANE_CTX
-                        const bool in_is_ch = (lam == 1);
-                        const bool in_pre = !in_is_ch && p.prefix_q > 0 && 2 * S >= p.prefix_q && phi < 2 * S;
-                        // (active lanes are valid ones: codeword g0 + lane / GS)
-                        const double *in0 = in_is_ch ? ch_row<ED>(p, cw_of_lane(lane), N) : nullptr;
-                        const double *pre_cw = in_pre ? p.pre + cw_of_lane(lane) * (size_t)(N - p.prefix_q + 1) : nullptr;
-                        const int pin = (in_is_ch || in_pre) ? 0 : pL.get(sh + 1);
-                        const size_t istr = in_pre ? 1 : 64;      // prefix layers are contiguous per codeword
-                        const double *gin = in_is_ch ? nullptr : (in_pre ? pre_cw + 1 + (size_t)(N - 4 * S)
-                                                                         : g_llr + (size_t)(2 * S - 2 * SL) * 64 + gbase + pin);
-                        uint32_t cb0 = 0, cb1 = 0;          // partial-sum bits for elements j.. and j+H..
-                        const uint32_t *cwp = nullptr;
-                        if (odd) {
-                            if (S <= 32) { cb0 = (uint32_t)(clsmall >> S); cb1 = cb0 >> H; }
-                            else cwp = g_cl + (size_t)(S / 32 - 2) * 64 + gbase + pC.get(sh);
-                        }
-                        // the body is instantiated once per address-space combination of its outputs: a pointer
-                        // that may be LDS or global degrades every access to a FLAT instruction, which waits on
-                        // vmcnt AND lgkmcnt (i.e. for every outstanding HBM store) before a dependent use
-                        auto fused_body = [&](const double *inp, double *out0, double *out1) {
-                            for (int j = 0; j < H; j += FU) {
-                                double a0[FU], b0[FU], a1[FU], b1[FU];
-                                if (in_is_ch) {
-#pragma unroll
-                                    for (int k = 0; k < FU; ++k) {
-                                        unsigned i0 = __brev((unsigned)(j + k)) >> (32 - n);
-                                        unsigned i1 = __brev((unsigned)(j + k + H)) >> (32 - n);
-                                        a0[k] = CH(in0, i0); b0[k] = CH(in0, i0 + 1);
-                                        a1[k] = CH(in0, i1); b1[k] = CH(in0, i1 + 1);
-                                    }
-                                } else {
-#pragma unroll
-                                    for (int k = 0; k < FU; ++k) {
-                                        a0[k] = inp[(size_t)(j + k) * istr];
-                                        b0[k] = inp[(size_t)(j + k + S) * istr];
-                                        a1[k] = inp[(size_t)(j + k + H) * istr];
-                                        b1[k] = inp[(size_t)(j + k + H + S) * istr];
-                                    }
-                                }
-                                if (odd && S > 32 && (j & 31) == 0) {
-                                    cb0 = cwp[(size_t)(j >> 5) * 64];
-                                    cb1 = (H >= 32) ? cwp[(size_t)((j + H) >> 5) * 64] : (cb0 >> H);
-                                }
-                                // element by element: (x0, x1) of layer lam -> stored -> y of layer lam+1 -> stored
-#pragma unroll
-                                for (int k = 0; k < FU; ++k) {
-                                    double x0, x1;
-                                    if (odd) {
-                                        const int bi = (S > 32) ? ((j + k) & 31) : (j + k);
-                                        x0 = GN(a0[k], b0[k], cb0, bi);
-                                        x1 = GN(a1[k], b1[k], cb1, bi);
-                                    } else {
-                                        x0 = FN(a0[k], b0[k]);
-                                        x1 = FN(a1[k], b1[k]);
-                                    }
-                                    out0[(size_t)(j + k) * 64] = x0;
-                                    out0[(size_t)(j + k + H) * 64] = x1;
-                                    out1[(size_t)(j + k) * 64] = FN(x0, x1);
-                                }
-                            }
-                        };
-                        // ---- four layers in one pass (lam .. lam+3, sizes S, S/2, S/4, S/8): element j of the lowest
-                        // one is a 3-stage f-tree over the eight elements j + m*S/8 of layer lam, so none of the three
-                        // intermediate layers is re-read from HBM by the f-visit below it (they are still written:
-                        // the later g-visits need them). 16 loads in flight per pass, as the two-layer body.
-                        // (measured and dropped: not storing layer 1's second half — the largest array — and re-deriving it
-                        // from the channel values at its only later reader, the g-visit of layer 2 at phi = 3N/4: -9 % HBM
-                        // bytes, but -1.7 % throughput; the re-derivation pass itself is slower than the traffic it saves)
-                        const bool tsrc = tbl && lam == 3 && phi >= S2;       // inputs come from the layer-2 table
-                        // GMM: bit k set = o_k is HBM-resident and passed as the UNIFORM base of its rows (the lane offset is added as a
-                        // 32-bit register offset: global_load/store with an SGPR base, no 64-bit VALU add per access)
-                        auto fused4 = [&](const double *inp, double *o0, double *o1, double *o2, double *o3, auto NTT, auto TSS, auto GMM) {
-                            constexpr bool TS = decltype(TSS)::value;
-                            constexpr int GM = decltype(GMM)::value;
-                            const uint32_t lb = (uint32_t)lane * 8u;
-                            const uint32_t lin = (uint32_t)(gbase + pin) * 8u;
-                            const char *inu = reinterpret_cast<const char *>(g_llr + (size_t)(2 * S - 2 * SL) * 64);      // source rows (uniform)
-                            auto st = [&](double *o, auto gbit, auto ntbit, size_t row, double val) {
-                                constexpr bool G_ = decltype(gbit)::value, N_ = decltype(ntbit)::value;
-                                double *q_ = G_ ? reinterpret_cast<double *>(reinterpret_cast<char *>(o) + row * 512 + lb) : o + row * 64;
-                                if (N_) __builtin_nontemporal_store(val, q_); else *q_ = val;
-                            };
-                            // streaming (non-temporal) accesses for the layers of size >= 64 (bit 0: input, 1: o0, 2: o1): they
-                            // are written once and read once or twice much later; the layers of size 16 and 32 stay cacheable
-                            // (measured +1.7 %)
-                            constexpr int NT = decltype(NTT)::value;
-                            const int E = S >> 3;
-                            uint32_t cw8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                            if (odd && S <= 32) cw8[0] = (uint32_t)(clsmall >> S);
-                            double a[8], b[8], v[8];
-                            const double *T2c = TS ? tab_w + (size_t)(lane / GS) * (size_t)(3 * N) + N : nullptr;
-                            const uint32_t *vp = TS ? g_v + gbase + pC.get(15) : nullptr;
-                            auto load8 = [&](int j) {
-                                if (TS) {
-#pragma unroll
-                                    for (int m = 0; m < 8; ++m) {
-                                        const int e0 = j + m * E, e1 = e0 + S;            // elements of layer 2
-                                        const uint32_t w0 = vp[(size_t)(e0 >> 3) * 64], w1 = vp[(size_t)(e1 >> 3) * 64];
-                                        a[m] = T2c[8 * e0 + ((w0 >> (4 * (e0 & 7))) & 7u)];
-                                        b[m] = T2c[8 * e1 + ((w1 >> (4 * (e1 & 7))) & 7u)];
-                                    }
-                                } else if (in_is_ch) {
-#pragma unroll
-                                    for (int m = 0; m < 8; ++m) {
-                                        const unsigned i0 = __brev((unsigned)(j + m * E)) >> (32 - n);
-                                        a[m] = CH(in0, i0); b[m] = CH(in0, i0 + 1);
-                                    }
-                                } else {
-                                    const int jj = j;
-#pragma unroll
-                                    for (int m = 0; m < 8; ++m) {
-#ifdef POLAR_SADDR
-                                        // (never the prefix buffer here: `deep` excludes it)
-                                        const double *pa = reinterpret_cast<const double *>(inu + (size_t)(jj + m * E) * 512 + lin);
-                                        const double *pb = reinterpret_cast<const double *>(inu + (size_t)(jj + m * E + S) * 512 + lin);
-                                        if (NT & 1) { a[m] = __builtin_nontemporal_load(pa); b[m] = __builtin_nontemporal_load(pb); }
-                                        else { a[m] = *pa; b[m] = *pb; }
-#else
-                                        if (NT & 1) { a[m] = __builtin_nontemporal_load(inp + (size_t)(jj + m * E) * istr); b[m] = __builtin_nontemporal_load(inp + (size_t)(jj + m * E + S) * istr); }
-                                        else { a[m] = inp[(size_t)(jj + m * E) * istr]; b[m] = inp[(size_t)(jj + m * E + S) * istr]; }
-#endif
-                                    }
-                                }
-                            };
-                            // (measured and dropped, round 3: an L2 prefetch of the NEXT pass's 16 source rows by ONE scattered
-                            // global_load_dword touching their 64 lines — no VGPRs, no wait: -1.5 %; the kernel is on the bandwidth
-                            // ceiling of its access pattern, asking earlier gains nothing)
-                            for (int j = 0; j < E; ++j) {
-                                load8(j);
-                                if (odd && S > 32 && (j & 31) == 0) {
-#pragma unroll
-                                    for (int m = 0; m < 8; ++m) cw8[m] = cwp[(size_t)((j + m * E) >> 5) * 64];
-                                }
-#pragma unroll
-                                for (int m = 0; m < 8; ++m) {
-                                    if (odd) v[m] = (S > 32) ? GN(a[m], b[m], cw8[m], (j + m * E) & 31) : GN(a[m], b[m], cw8[0], j + m * E);
-                                    else v[m] = FN(a[m], b[m]);
-                                }
-                                // (issuing the next pass's loads here, ahead of the 15 stores, was measured: -15 % — the
-                                // double-buffered inputs do not fit the 128-VGPR budget)
-                                const int js = j;
-                                typedef std::integral_constant<bool, (GM & 1) != 0> G0; typedef std::integral_constant<bool, (GM & 2) != 0> G1;
-                                typedef std::integral_constant<bool, (GM & 4) != 0> G2; typedef std::integral_constant<bool, (GM & 8) != 0> G3;
-                                typedef std::integral_constant<bool, (NT & 2) != 0> N0; typedef std::integral_constant<bool, (NT & 4) != 0> N1;
-                                typedef std::integral_constant<bool, (NT & 8) != 0> N2; typedef std::integral_constant<bool, false> N3;
-#pragma unroll
-                                for (int m = 0; m < 8; ++m) st(o0, G0{}, N0{}, (size_t)(js + m * E), v[m]);
-#pragma unroll
-                                for (int m = 0; m < 4; ++m) { v[m] = FN(v[m], v[m + 4]); st(o1, G1{}, N1{}, (size_t)(js + m * E), v[m]); }
-#pragma unroll
-                                for (int m = 0; m < 2; ++m) { v[m] = FN(v[m], v[m + 2]); st(o2, G2{}, N2{}, (size_t)(js + m * E), v[m]); }
-                                v[0] = FN(v[0], v[1]);
-                                st(o3, G3{}, N3{}, (size_t)j, v[0]);
-                                leaf = v[0];            // (the leaf value when S/8 == 1)
-                            }
-                        };
-#define POLAR_GROW(T) (g_llr + (size_t)((T) - 2 * SL) * 64 + lane)
-#define POLAR_LROW(T) (lds_llr + (size_t)((T) - 1) * 64 + lane)
-                        if (deep) {
-                            const int Q = S / 4, E8 = S / 8;
-                            // (also streaming the layer of size 32, so that only the layer of size 16 competes for the L2: -0.5 %)
-#define POLAR_NTM(x) std::integral_constant<int, (x)>{}
-                            typedef std::integral_constant<bool, false> TS0;
-#ifdef POLAR_SADDR
-#define POLAR_GOUT(T) (g_llr + (size_t)((T) - 2 * SL) * 64)
-#define POLAR_GMK(x) std::integral_constant<int, (x)>{}
-#else
-#define POLAR_GOUT(T) POLAR_GROW(T)
-#define POLAR_GMK(x) std::integral_constant<int, 0>{}
-#endif
-                            if (tsrc) fused4(gin, POLAR_GOUT(S), POLAR_GOUT(H), POLAR_GOUT(Q), POLAR_GOUT(E8), POLAR_NTM(6), std::integral_constant<bool, true>{}, POLAR_GMK(15));
-                            else if (E8 > SL) fused4(gin, POLAR_GOUT(S), POLAR_GOUT(H), POLAR_GOUT(Q), POLAR_GOUT(E8), POLAR_NTM(7), TS0{}, POLAR_GMK(15));      // S >= 128
-                            else if (Q > SL) fused4(gin, POLAR_GOUT(S), POLAR_GOUT(H), POLAR_GOUT(Q), POLAR_LROW(E8), POLAR_NTM(3), TS0{}, POLAR_GMK(7));   // S = 64
-                            else if (H > SL) fused4(gin, POLAR_GOUT(S), POLAR_GOUT(H), POLAR_LROW(Q), POLAR_LROW(E8), POLAR_NTM(1), TS0{}, POLAR_GMK(3));   // S = 32: input 64
-                            else if (S > SL) fused4(gin, POLAR_GOUT(S), POLAR_LROW(H), POLAR_LROW(Q), POLAR_LROW(E8), POLAR_NTM(0), TS0{}, POLAR_GMK(1));                 // S = 16: input 32
-                            else fused4(gin, POLAR_LROW(S), POLAR_LROW(H), POLAR_LROW(Q), POLAR_LROW(E8), std::integral_constant<int, 0>{}, TS0{}, POLAR_GMK(0));        // S = 8: input 16
-#undef POLAR_GOUT
-#undef POLAR_GMK
-#undef POLAR_NTM
-                            pL.set(sh - 2, lig);
-                            pL.set(sh - 3, lig);
-                        }
-                        else if (S <= SL) fused_body(gin, POLAR_LROW(S), POLAR_LROW(H));
-                        else if (H <= SL) fused_body(gin, POLAR_GROW(S), POLAR_LROW(H));
-                        else fused_body(gin, POLAR_GROW(S), POLAR_GROW(H));
-#undef POLAR_GROW
-#undef POLAR_LROW
-                        pL.set(sh, lig);
-                        pL.set(sh - 1, lig);
-                    }
-                    wave_mem_fence();
-                    PROF(odd ? 1 : 2)
-#ifdef POLAR_SLOTHIST
-                    if (GS == 32 && p.pm_out && lane == 0 && actw) {      // f-visits of this pass fed from registers (the path's own values)
-                        u64 *hb = reinterpret_cast<u64 *>(p.pm_out) + 64 + (size_t)24 * 40;
-                        for (int d_ = 1; d_ <= (deep ? 3 : 1); ++d_) if ((S >> d_) > SL) atomicAdd(hb + (sh - d_), 1ull);
-                    }
-#endif
-                    lam += deep ? 3 : 1;          // layers lam+1 (.. lam+3) are done
-                    continue;
-                }
-                // ---- both layers in LDS (the bottom of the tree, visited at almost every leaf): plain ds_read /
-                // ds_write on provably-LDS pointers, all inputs of the visit loaded before the first f
-                if (lam > 1 && 2 * S <= SL) {
-                    // the f-visits of the layers below follow immediately (phi is a multiple of S): they are taken
-                    // from registers in the same pass — `below` more layers, down to the leaf or the rate-0 block
-                    // (not at the resume point of the all-frozen prefix, where phi is not a multiple of S)
-                    const int below = ((phi & (S - 1)) == 0) ? lam_stop - lam : 0;
-                    if (active) {
-                        LANE_CTX
-                        const double *li = lds_llr + (size_t)(2 * S - 1) * 64 + gbase + pL.get(sh + 1);
-                        double *lo = lds_llr + (size_t)(S - 1) * 64 + lane;
-                        const uint32_t cb = odd ? (uint32_t)(clsmall >> S) : 0u;
-                        auto small = [&](auto SS) {
-                            constexpr int S_ = decltype(SS)::value;
-                            double a[S_], b[S_], r[S_];
-#pragma unroll
-                            for (int j = 0; j < S_; ++j) { a[j] = li[(size_t)j * 64]; b[j] = li[(size_t)(j + S_) * 64]; }
-#pragma unroll
-                            for (int j = 0; j < S_; ++j) r[j] = odd ? GN(a[j], b[j], cb, j) : FN(a[j], b[j]);
-                            // (the layer of size 1 — the leaf value — is consumed from the register: nobody reads it back)
-                            if (S_ > 1 || !POLAR_SKIP_L1) {
-#pragma unroll
-                                for (int j = 0; j < S_; ++j) lo[(size_t)j * 64] = r[j];
-                            }
-                            // layer of size T = S_ >> d from the one above (registers), stored for its later g-visit
-                            auto down = [&](auto TT) {
-                                constexpr int T = decltype(TT)::value;
-                                double *lt = lds_llr + (size_t)(T - 1) * 64 + lane;
-#pragma unroll
-                                for (int j = 0; j < T; ++j) { r[j] = FN(r[j], r[j + T]); if (T > 1 || !POLAR_SKIP_L1) lt[(size_t)j * 64] = r[j]; }
-                            };
-                            if constexpr (S_ >= 2) { if (below >= 1) down(std::integral_constant<int, S_ / 2>{}); }
-                            if constexpr (S_ >= 4) { if (below >= 2) down(std::integral_constant<int, S_ / 4>{}); }
-                            if constexpr (S_ >= 8) { if (below >= 3) down(std::integral_constant<int, S_ / 8>{}); }
-                            if constexpr (S_ >= 16) { if (below >= 4) down(std::integral_constant<int, S_ / 16>{}); }
-                            leaf = r[0];            // (the leaf LLR when the chain reached the layer of size 1)
-                        };
-                        if (S == 1) small(std::integral_constant<int, 1>{});
-                        else if (S == 2) small(std::integral_constant<int, 2>{});
-                        else if (S == 4) small(std::integral_constant<int, 4>{});
-                        else if (S == 8) small(std::integral_constant<int, 8>{});
-                        else small(std::integral_constant<int, 16>{});      // (lds_log = 5)
-                        for (int d = 0; d <= below; ++d) if (sh - d > 0 || !POLAR_SKIP_L1) pL.set(sh - d, lig);
-                    }
-                    wave_mem_fence();
-                    PROF(S >= 4 ? 3 : 4)
-                    lam += below;
-                    continue;
-                }
-                if (active) {
-                    LANE_CTX
-                    // input layer lam-1 (size 2S): 0 = channel LLRs, else scratch/LDS slot
-                    const int pin = (lam > 1) ? pL.get(sh + 1) : 0;
-                    const double *inp;   // element j at inp[j*istride]
-                    size_t istride;
-                    const bool in_is_ch = (lam == 1);
-                    const bool in_pre = !in_is_ch && p.prefix_q > 0 && 2 * S >= p.prefix_q && phi < 2 * S;
-                    const double *in0 = in_is_ch ? ch_row<ED>(p, cw_of_lane(lane), N) : nullptr;
-                    const double *pre_cw = in_pre ? p.pre + cw_of_lane(lane) * (size_t)(N - p.prefix_q + 1) : nullptr;
-                    constexpr bool in_lds = false;          // (LDS inputs were handled above)
-                    istride = 64;
-                    if (in_pre) { inp = pre_cw + 1 + (size_t)(N - 4 * S); istride = 1; }
-                    else if (!in_is_ch) inp = g_llr + (size_t)(2 * S - 2 * SL) * 64 + gbase + pin;
-                    else inp = nullptr;
-                    const bool out_lds = (S <= SL);
-                    auto generic_body = [&](double *outp) {
-                    // partial sums for g (column 0 of C_lam)
-                    uint32_t cbits = 0;
-                    const uint32_t *cwp = nullptr;
-                    if (odd) {
-                        if (S <= 32) cbits = (uint32_t)(clsmall >> S);
-                        else cwp = g_cl + (size_t)(S / 32 - 2) * 64 + gbase + pC.get(sh);
-                    }
-                    if (PIPE && S >= 16 && !in_lds) {
-                        // source in HBM/L2 (channel LLRs or a scratch layer): software-pipelined,
-                        // 8 elements (16 loads, 8 KiB per wave) in flight ahead of the compute
-                        constexpr int U = 8;
-                        double a0[U], b0[U], a1[U], b1[U];
-                        auto load = [&](int j, double (&a)[U], double (&b)[U]) {
-                            if (in_is_ch) {
-#pragma unroll
-                                for (int k = 0; k < U; ++k) {
-                                    // position j <-> reference beta = bitrev_n(j); (j, j+N/2) <-> (2b', 2b'+1)
-                                    unsigned idx = __brev((unsigned)(j + k)) >> (32 - n);
-                                    a[k] = CH(in0, idx);
-                                    b[k] = CH(in0, idx + 1);
-                                }
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < U; ++k) {
-                                    a[k] = inp[(size_t)(j + k) * istride];
-                                    b[k] = inp[(size_t)(j + k + S) * istride];
-                                }
-                            }
-                        };
-                        auto comp = [&](int j, double (&a)[U], double (&b)[U]) {
-                            double r[U];
-                            if (odd) {
-                                if (S > 32 && (j & 31) == 0) cbits = cwp[(size_t)(j >> 5) * 64];
-#pragma unroll
-                                for (int k = 0; k < U; ++k) r[k] = GN(a[k], b[k], cbits, (j + k) & 31);
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < U; ++k) r[k] = FN(a[k], b[k]);
-                            }
-#pragma unroll
-                            for (int k = 0; k < U; ++k) outp[(size_t)(j + k) * 64] = r[k];
-                        };
-                        load(0, a0, b0);
-                        for (int j = 0; j < S; j += 2 * U) {
-                            load(j + U, a1, b1);
-                            comp(j, a0, b0);
-                            if (j + 2 * U < S) load(j + 2 * U, a0, b0);
-                            comp(j + U, a1, b1);
-                        }
-                    } else if (S >= 4) {
-                        for (int j = 0; j < S; j += 4) {
-                            double a[4], b[4], r[4];
-                            if (in_is_ch) {
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) {
-                                    unsigned idx = __brev((unsigned)(j + k)) >> (32 - n);
-                                    a[k] = CH(in0, idx);
-                                    b[k] = CH(in0, idx + 1);
-                                }
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) {
-                                    a[k] = inp[(size_t)(j + k) * istride];
-                                    b[k] = inp[(size_t)(j + k + S) * istride];
-                                }
-                            }
-                            if (odd) {
-                                if (S > 32 && (j & 31) == 0) cbits = cwp[(size_t)(j >> 5) * 64];
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) r[k] = GN(a[k], b[k], cbits, (j + k) & 31);
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) r[k] = FN(a[k], b[k]);
-                            }
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) outp[(size_t)(j + k) * 64] = r[k];
-                        }
-                    } else {
-                        for (int j = 0; j < S; ++j) {
-                            double a, b;
-                            if (in_is_ch) {
-                                unsigned idx = __brev((unsigned)j) >> (32 - n);
-                                a = CH(in0, idx);
-                                b = CH(in0, idx + 1);
-                            } else {
-                                a = inp[(size_t)j * istride];
-                                b = inp[(size_t)(j + S) * istride];
-                            }
-                            double r = odd ? GN(a, b, cbits, j) : FN(a, b);
-                            outp[(size_t)j * 64] = r;
-                            leaf = r;
-                        }
-                    }
-                    };
-                    if (out_lds) generic_body(lds_llr + (size_t)(S - 1) * 64 + lane);
-                    else generic_body(g_llr + (size_t)(S - 2 * SL) * 64 + lane);
-                    pL.set(sh, lig);
-                }
-                wave_mem_fence();
-                PROF(S > SL ? (odd ? 1 : 2) : (S >= 4 ? 3 : 4))
-            }
-
-
-            if (zb) {
-                // ---- rate-0 block: Z = 2^zb consecutive frozen leaves whose subtree hangs off the layer of
-                // size Z that was just computed. Every decision inside is the frozen 0, so the Z leaf LLRs
-                // are a fixed f/g dataflow of that layer (g with u = 0): evaluated level by level in
-                // registers (ILP Z/2) instead of Z sequential leaf steps; the path metric is then updated
-                // leaf by leaf in order (PolarCode.cpp:475-487), and the block's partial sums (Z zeros) are
-                // handed to the layer of size Z exactly as the last leaf's recursivelyUpdateC would.
-                const int Z = 1 << zb;
-                LANE_CTX
-                // one 4-leaf sub-block: values v0..v3 of a size-4 node -> leaves (f,f) (f,g) (g,f) (g,g), then
-                // the metric update of those four leaves in order
-                auto block4 = [&](double v0, double v1, double v2, double v3) {
-                    double lf[4] = {0, 0, 0, 0};
-                    if (active) {
-                        double a0, a1;
-                        FN2(v0, v2, v1, v3, a0, a1);
-                        const double b0 = GN(v0, v2, 0u, 0), b1 = GN(v1, v3, 0u, 0);
-                        FN2(a0, a1, b0, b1, lf[0], lf[2]);
-                        lf[1] = GN(a0, a1, 0u, 0); lf[3] = GN(b0, b1, 0u, 0);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        bool ng; double alz, sneg, spos;
-                        leaf_terms<ED>(lf[i], active, actw, tb, ng, alz, sneg, spos);
-                        if (active) pm += ng ? spos : sneg;
-                    }
-                };
-                // (one instantiation per address space of the source: a maybe-LDS-maybe-global pointer would
-                // turn the loads into FLAT instructions that wait for every outstanding memory operation)
-                auto rate0 = [&](const double *yp, auto STR_) {
-                    constexpr int YS = decltype(STR_)::value;         // distance between the elements of the layer (LAT: GS)
-                    if (zb == 3) {
-                        double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
-                        if (active) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const double lo = yp[(size_t)j * YS], hi = yp[(size_t)(j + 4) * YS];
-                                a[j] = FN(lo, hi);
-                                b[j] = GN(lo, hi, 0u, 0);
-                            }
-                        }
-                        block4(a[0], a[1], a[2], a[3]);
-                        block4(b[0], b[1], b[2], b[3]);
-                    } else {
-                        double y[4] = {0, 0, 0, 0};
-                        if (active) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) y[j] = yp[(size_t)j * YS];
-                        }
-                        block4(y[0], y[1], y[2], y[3]);
-                    }
-                };
-                if constexpr (LAT) rate0(lat_a + (size_t)(Z - 1) * GS + lig, std::integral_constant<int, GS>{});
-                else if (Z <= SL) rate0(lds_llr + (size_t)(Z - 1) * 64 + lane, std::integral_constant<int, 64>{});
-                else rate0(g_llr + (size_t)(Z - 2 * SL) * 64 + lane, std::integral_constant<int, 64>{});
-                const int nu = phi >> zb;                     // node index of the block at its layer
-                if ((nu & 1) == 0) {
-                    if (active) clsmall &= ~((((u64)1 << Z) - 1ull) << Z);   // column 0 of that layer := 0
-                } else {
-                    update_c(Z, 0u, nu);
-                }
-                wave_mem_fence();
-                PROF(5)
-                phi += Z - 1;
-                continue;
-            }
-            // ---------------- leaf: frozen / unfrozen ----------------
-            LANE_CTX
-            const u64 below = (1ull << lig) - 1ull;
-            const bool frozen = (ctl & 1u) != 0;      // wave-uniform
-            unsigned ubit = 0;
-            if (frozen) {
-                // continuePaths_FrozenBit: PolarCode.cpp:475-487
-                // PM += log(1+e^-llr): exactly 0 for llr >= 37, exactly |llr| (+0) for llr <= -37
-                bool ng; double alz, sneg, spos;
-                leaf_terms<ED>(leaf, active, actw, tb, ng, alz, sneg, spos);
-                if (active) pm += ng ? spos : sneg;
-            } else {
-                // continuePaths_UnfrozenBit: PolarCode.cpp:489-607
-                const u64 actm = (actw >> gbase) & gmask;
-                const int nact = __popcll(actm);
-                const int rho = (2 * nact < L) ? 2 * nact : L;
-                // ---- fast path (exact): list full and every "good" fork (the bit the leaf LLR favours)
-                // beats every "bad" fork of every path => the L survivors are the L good forks, nobody
-                // is killed or cloned.  good metric = PM + log(1+e^-|llr|) (the same sum the general
-                // path computes); bad metric = PM + log(1+e^|llr|) >= (PM + |llr|)(1 - 2^-40).
-                bool lneg; double al;                      // llr < 0, |llr|
-                double gm = -__builtin_inf(), bl = __builtin_inf();
-                double sneg, spos;                         // log(1+e^-|llr|), log(1+e^|llr|)
-                // (a logarithm-free lower bound of |llr| for this test — exponent and mantissa of E — was measured:
-                // -1.5 %, the bound is short by up to 0.06 and sends more steps down the ranking path)
-                leaf_terms<ED>(leaf, active, actw, tb, lneg, al, sneg, spos);
-                if constexpr (ED) {
-                    // a leaf the host marked as weak (control word bit 8: no construction for an ordinary channel leaves it
-                    // unfrozen) that comes out below 1e-8: the reference decides on the rounding noise of its own arithmetic
-                    // there, which the LLR-domain kernel follows much further down than this one -> fallback pass
-                    if (POLAR_UNLIKELY2(ctl & 0x100u)) guard |= __ballot(active && fabs(leaf) > 0.99999999 && fabs(leaf) <= 1.0);
-                }
-                if (active) {
-                    gm = pm + sneg;
-                    bl = (pm + al) * 0.99999999999909050530;
-                }
-                // cheap sufficient test first: the metrics are non-negative doubles, so their HIGH words
-                // order like unsigned integers; max / min of those over the group cost one DPP-fused integer
-                // instruction per stage and no LDS traffic. Distinct high words decide gmax < bmin for
-                // certain; only when they collide (|gmax - bmin| < 2^-20 relative) or the test fails are the
-                // exact fp64 reductions run.
-                bool fast;
-                {
-                    unsigned gh = active ? (unsigned)__double2hiint(gm) : 0u;
-                    unsigned bh = active ? (unsigned)__double2hiint(bl) : 0xFFFFFFFFu;
-                    group_max_min_u32<GS>(gh, bh);
-                    const u64 m_ok = __builtin_amdgcn_sicmp(nact, 0, 32) | (__builtin_amdgcn_sicmp(nact, L, 32) & __builtin_amdgcn_uicmp(gh, bh, 36));   // EQ, EQ, ULT
-                    fast = ((m_ok | ~group_result_rows<GS>()) == ~0ull);
-                }
-                double gmax = 0.0;
-                if (!fast) {
-                    gmax = group_reduce<GS, true>(gm, lane);
-                    const double bmin = group_reduce<GS, false>(bl, lane);
-                    fast = wave_all((nact == 0) || (nact == L && gmax < bmin));
-                }
-                PROF_CNT(8, 1)
-                PROF(16)
-                if (fast) {      // (marking this likely — the ranking path out of line — measured -0.5 %)
-                    PROF_CNT(9, 1)
-#ifdef POLAR_MARGIN
-                    {
-                        const double gx = group_reduce<GS, true>(active ? gm : -__builtin_inf(), lane);
-                        const double bx = group_reduce<GS, false>(active ? pm + spos : __builtin_inf(), lane);
-                        if (nact == L) mingap = __builtin_fmin(mingap, bx - gx);
-                    }
-#endif
-                    if (active) {
-                        ubit = lneg ? 1u : 0u;
-                        pm = gm;
-                        hword |= ubit << (t & 31);
-                    }
-                    PROF(17)
-                } else {
-                double pf0 = __builtin_nan(""), pf1 = __builtin_nan("");
-                if (active) {
-                    pf0 = -(pm + (lneg ? spos : sneg));     // -(PM + log(1+e^-llr)), PolarCode.cpp:505
-                    pf1 = -(pm + (lneg ? sneg : spos));     // -(PM + log(1+e^llr)),  PolarCode.cpp:506
-                }
-                bool c0 = active, c1 = active;
-                const bool need = (2 * nact > L);          // otherwise every fork continues
-                const bool full = (nact == L);
-                if (POLAR_LIKELY2(!wave_any(need && !full))) {
-                    // List full (the usual case). Rank = number of better forks in the reference's order
-                    // (metric desc = PM asc, fork index asc on ties, PolarCode.cpp:528-553). A bad fork
-                    // whose lower bound is worse than every good fork (bl > gmax) can neither survive nor
-                    // outrank a survivor, so only the L good forks and the few "competitive" bad forks
-                    // are compared against: 32 LDS broadcasts + a short scalar loop instead of 64.
-                    const bool goodbit = lneg;                       // bit the leaf LLR favours
-                    const double mg = goodbit ? -pf1 : -pf0;                // PM of my good / bad fork
-                    const double mb = goodbit ? -pf0 : -pf1;
-                    const bool cbad = active && full && !(bl > gmax);
-                    const u64 cbm = __ballot(cbad);
-                    bool sg, sbd;
-                    if constexpr (GS == 32) {
-                        // Two groups of 32 lanes. (1) Every competitive bad fork is ranked on the SCALAR unit: its metric
-                        // is read into SGPRs, four wave-wide compares give the masks of the good / competitive bad forks
-                        // ordered before it (metric, then fork index 2*path + bit), a population count gives its rank.
-                        // (2) The list stays at L, so k surviving bad forks displace the k WORST good forks of the
-                        // group; those are peeled off by a DPP maximum over the metrics' high words (non-negative
-                        // doubles order like their bit patterns), all lanes sharing the maximal high word at once
-                        // when k allows, otherwise the low words and lane numbers decide, on the scalar unit.
-                        const u64 actm64 = actw;
-                        const u64 gbm = __ballot(goodbit);
-                        u64 surv = 0;
-                        PROF_CNT(10, 1)
-                        PROF_CNT(11, __popcll(cbm))
-                        for (u64 mi = cbm; mi; mi &= mi - 1) {
-                            const int l_ = __builtin_ctzll(mi);
-                            const double s_mb = readlane_d(mb, l_);
-                            const u64 grp = 0xFFFFFFFFull << (l_ & 32);
-                            const u64 blw = ((1ull << l_) - 1ull) & grp;              // paths below l_ in its group
-                            const u64 self_first = ~gbm & (1ull << l_);              // own good fork is bit 0: lower index
-                            const u64 lt_g = __builtin_amdgcn_fcmp(mg, s_mb, 4), eq_g = __builtin_amdgcn_fcmp(mg, s_mb, 1);
-                            const u64 lt_b = __builtin_amdgcn_fcmp(mb, s_mb, 4), eq_b = __builtin_amdgcn_fcmp(mb, s_mb, 1);
-                            const int r = __popcll((lt_g | (eq_g & (blw | self_first))) & grp & actm64) +
-                                          __popcll((lt_b | (eq_b & blw)) & grp & cbm);
-                            if (r < L) surv |= 1ull << l_;
-                        }
-                        PROF(18)
-                        int k0 = __popcll(surv & 0xFFFFFFFFull), k1 = __popcll(surv >> 32);
-                        u64 alive = actm64;
-                        const unsigned khi = (unsigned)__double2hiint(mg) + 1u, klo = (unsigned)__double2loint(mg);
-                        auto peel = [&](u64 e, int &k) {
-                            const int ne = __popcll(e);
-                            if (ne == 0) { k = 0; return; }
-                            if (ne <= k) { alive &= ~e; k -= ne; return; }
-                            for (; k > 0; --k) {                                       // equal high words: low word, then lane
-                                int best = -1; unsigned blo = 0;
-                                for (u64 q = e; q; q &= q - 1) {
-                                    const int l_ = __builtin_ctzll(q);
-                                    const unsigned lo_ = (unsigned)__builtin_amdgcn_readlane((int)klo, l_);
-                                    if (best < 0 || lo_ >= blo) { best = l_; blo = lo_; }
-                                }
-                                e &= ~(1ull << best);
-                                alive &= ~(1ull << best);
-                            }
-                        };
-                        while (k0 | k1) {
-                            const unsigned h0 = __builtin_amdgcn_inverse_ballot_w64(alive) ? khi : 0u;
-                            unsigned h = h0;
-                            group_max_u32<GS>(h);
-                            const unsigned m0 = (unsigned)__builtin_amdgcn_readlane((int)h, 31), m1 = (unsigned)__builtin_amdgcn_readlane((int)h, 63);
-                            const u64 eq = __ballot(h0 == (lane < 32 ? m0 : m1)) & alive;
-                            if (k0) peel(eq & 0xFFFFFFFFull, k0);
-                            if (k1) peel(eq & 0xFFFFFFFF00000000ull, k1);
-                        }
-                        sg = __builtin_amdgcn_inverse_ballot_w64(alive);
-                        sbd = __builtin_amdgcn_inverse_ballot_w64(surv);
-                        PROF_CNT(13, (__popcll(surv & 0xFFFFFFFFull) > __popcll(surv >> 32)) ? __popcll(surv & 0xFFFFFFFFull) : __popcll(surv >> 32))
-                        PROF(19)
-                    } else {
-                        sortbuf[lane] = mg;
-                        wave_mem_fence();
-                        int rg = 0, rb = 0;
-                        const double *sb = sortbuf + gbase;
-                        // good fork of path i (index 2i + bit) vs my forks (indices 2*lig + ...): it precedes them
-                        // on a tie exactly when i < lig (for i == lig see below), so the tie-break folds into the
-                        // choice between "<=" and "<"; comparisons produce wave masks, combined on the scalar unit
-#pragma unroll 8
-                        for (int i = 0; i < GS; ++i) {
-                            const double v = sb[i];
-                            const u64 below_me = __ballot(lig > i);                    // lanes for which i < lig
-                            const u64 lt_g = __builtin_amdgcn_fcmp(v, mg, 4), le_g = __builtin_amdgcn_fcmp(v, mg, 5);
-                            const u64 lt_b = __builtin_amdgcn_fcmp(v, mb, 4), le_b = __builtin_amdgcn_fcmp(v, mb, 5);
-                            rg += (int)__builtin_amdgcn_inverse_ballot_w64((le_g & below_me) | (lt_g & ~below_me));
-                            rb += (int)__builtin_amdgcn_inverse_ballot_w64((le_b & below_me) | (lt_b & ~below_me));
-                        }
-                        // i == lig: my own good fork is never counted against itself (v < mg is false); against my
-                        // bad fork the strict part (mg < mb) was counted above, a tie goes to the lower fork index
-                        rb += (mg == mb && !goodbit) ? 1 : 0;
-                        PROF(18)
-                        // competitive bad forks (few at low SNR, up to all L when garbage paths fill the list):
-                        // same scheme from the second half of the exchange buffer, iterations without a
-                        // competitive bad fork in any group are skipped on the scalar unit
-                        sortbuf[64 + lane] = mb;
-                        wave_mem_fence();
-                        const double *sbb = sortbuf + 64 + gbase;
-                        u64 any_i = 0;                                       // bit i: some group has a competitive bad fork i
-#pragma unroll
-                        for (int g = 0; g < 64 / GS; ++g) any_i |= (cbm >> (g * GS)) & gmask;
-                        PROF_CNT(10, 1)
-                        PROF_CNT(11, __popcll(any_i))
-#ifdef POLAR_PROFILE
-                        {   // statistics only: good forks that some bad fork of their group could displace
-                            const double bmin_true = group_reduce<GS, false>(active ? mb : __builtin_inf(), lane);
-                            const u64 cgm = __ballot(active && !(mg < bmin_true));
-                            u64 any_g = 0;
-                            for (int g = 0; g < 64 / GS; ++g) any_g |= (cgm >> (g * GS)) & gmask;
-                            PROF_CNT(12, __popcll(any_g))
-                        }
-#endif
-                        for (u64 mi = any_i; mi; mi &= mi - 1) {
-                            const int i = __builtin_ctzll(mi);
-                            const double v = sbb[i];
-                            const u64 mine = __ballot(((cbm >> gbase) >> i) & 1ull);      // lanes whose group's bad fork i competes
-                            const u64 below_me = __ballot(lig > i);
-                            const u64 lt_g = __builtin_amdgcn_fcmp(v, mg, 4), le_g = __builtin_amdgcn_fcmp(v, mg, 5);
-                            const u64 lt_b = __builtin_amdgcn_fcmp(v, mb, 4), le_b = __builtin_amdgcn_fcmp(v, mb, 5);
-                            rg += (int)__builtin_amdgcn_inverse_ballot_w64(((le_g & below_me) | (lt_g & ~below_me)) & mine);
-                            rb += (int)__builtin_amdgcn_inverse_ballot_w64(((le_b & below_me) | (lt_b & ~below_me)) & mine);
-                        }
-                        // i == lig: my own bad fork against my good fork: mb < mg cannot hold, a tie goes to the
-                        // lower fork index (the bad fork has the lower index when the good bit is 1)
-                        rg += (cbad && mg == mb && goodbit) ? 1 : 0;
-                        PROF(19)
-#ifdef POLAR_PROFILE
-                        {   // statistics only: surviving bad forks (= killed good forks) per group, max over the groups
-                            const u64 sbm = __ballot(cbad && rb < L);
-                            int kmax = 0, ktot = 0;
-                            for (int g = 0; g < 64 / GS; ++g) { const int k_ = __popcll((sbm >> (g * GS)) & gmask); kmax = k_ > kmax ? k_ : kmax; ktot += k_; }
-                            PROF_CNT(13, kmax)
-                            PROF_CNT(14, kmax <= 4 ? 1 : 0)
-                            PROF_CNT(15, kmax == 0 ? 1 : 0)
-                        }
-#endif
-                        sg = active && (rg < L);
-                        sbd = cbad && (rb < L);
-                    }
-                    if (full) {
-                        c0 = goodbit ? sbd : sg;
-                        c1 = goodbit ? sg : sbd;
-                    }
-#ifdef POLAR_MARGIN
-                    {
-                        const double ninf = -__builtin_inf(), pinf = __builtin_inf();
-                        const double sv = __builtin_fmax(sg ? mg : ninf, sbd ? mb : ninf);
-                        const double kv = __builtin_fmin((active && !sg) ? mg : pinf, (active && !sbd) ? mb : pinf);
-                        const double sx = group_reduce<GS, true>(sv, lane), kx = group_reduce<GS, false>(kv, lane);
-                        if (full) mingap = __builtin_fmin(mingap, kx - sx);
-                    }
-#endif
-                    wave_mem_fence();
-                } else {
-                    sortbuf[2 * lane] = pf0;
-                    sortbuf[2 * lane + 1] = pf1;
-                    wave_mem_fence();
-                    int r0 = 0, r1 = 0;
-                    const double *sb = sortbuf + 2 * gbase;
-                    const int i0 = 2 * lig;
-                    // stable rank: value descending, fork index 2l+b ascending on ties
-                    // (PolarCode.cpp:528-553: "> threshold" first, then "== threshold" in index order)
-#pragma unroll 4
-                    for (int i = 0; i < 2 * GS; ++i) {
-                        const double v = sb[i];
-                        r0 += (i < i0) ? (v >= pf0) : (v > pf0);
-                        r1 += (i <= i0) ? (v >= pf1) : (v > pf1);
-                    }
-                    if (need) {
-                        c0 = active && (r0 < rho);
-                        c1 = active && (r1 < rho);
-                    }
-                    wave_mem_fence();
-                }
-                // kills (ascending l) push, then clones (ascending l) pop: PolarCode.cpp:555-570
-                const bool kill = active && !c0 && !c1;
-                const bool both = c0 && c1;
-                const u64 km = (__ballot(kill) >> gbase) & gmask;
-                const u64 bm = (__ballot(both) >> gbase) & gmask;
-                srcof[lane] = (unsigned char)lig;
-                if (POLAR_LIKELY2(wave_all(!active || full))) {
-                    // list full before the step => #kills == #clones: the kills are pushed (ascending l) and
-                    // popped right back (LIFO) by the clones in ascending l, i.e. the r-th cloner revives the
-                    // r-th LARGEST killed index; stack pointer and the entries below are untouched. One LDS
-                    // round trip: cloners post their index by rank, killed lanes pick theirs up.
-                    if (both) stackv[gbase + __popcll(bm & below)] = (unsigned char)lig;           // rank r -> cloner
-                    wave_mem_fence();
-                    if (kill) srcof[lane] = stackv[gbase + __popcll(km >> 1 >> lig)];             // #killed above me = my rank from the top
-                    wave_mem_fence();
-                } else {
-                    if (kill) stackv[gbase + sp + __popcll(km & below)] = (unsigned char)lig;
-                    sp += __popcll(km);
-                    wave_mem_fence();
-                    if (both) {
-                        int lp = stackv[gbase + sp - 1 - __popcll(bm & below)];
-                        srcof[gbase + lp] = (unsigned char)lig;
-                    }
-                    sp -= __popcll(bm);
-                    wave_mem_fence();
-                }
-                const int src = srcof[lane];
-                const bool is_clone = (src != lig);
-                PROF(20)
-                // PM of the surviving forks: PM + log(1+exp(-+llr)) is the very sum whose negation
-                // was ranked (PolarCode.cpp:580-582, 593, 601)
-                double pm_new = c0 ? -pf0 : -pf1;
-                ubit = c0 ? 0u : 1u;
-                if (wave_any(is_clone)) {
-                    const int sl = gbase + src;
-                    double pm1 = shfl_d(-pf1, sl);
-                    u64 a0 = shfl_u64(pL.lo, sl), a1 = shfl_u64(pL.hi, sl);
-                    u64 b0 = shfl_u64(pC.lo, sl), b1 = shfl_u64(pC.hi, sl);
-                    u64 cs = shfl_u64(clsmall, sl);
-                    uint32_t hw = __shfl(hword, sl, 64);
-                    int og = __shfl(origin, sl, 64);
-                    if (is_clone) {
-                        pm_new = pm1; ubit = 1u;
-                        pL.lo = a0; pL.hi = a1; pC.lo = b0; pC.hi = b1;
-                        clsmall = cs; hword = hw; origin = og;
-                    }
-                }
-                active = (active && !kill) || is_clone;
-                actw = __ballot(active);
-                if (active) {
-                    pm = pm_new;
-                    hword |= ubit << (t & 31);
-                } else {
-                    pm = 0.0;   // killPath zeroes the metric (PolarCode.cpp:293-294)
-                }
-                PROF(21)
-                }   // general path
-                // every 32 unfrozen steps the decision word is stored together with the slot (`origin`) that
-                // holds this path's previous word: a linked list per path, walked once at the end, so that
-                // neither clones nor flushes ever copy history (the reference copies it on every clone,
-                // PolarCode.cpp:574)
-                if (POLAR_UNLIKELY2((t & 31) == 31)) {
-                    const int w = (int)(t >> 5);
-                    if (active) {
-                        g_hist[(size_t)w * CST + POLAR_CL] = hword;
-                        g_horg[(size_t)w * CST + POLAR_CL] = (uint32_t)origin;
-                        origin = lig;
-                        hword = 0;
-                    }
-                    wave_mem_fence();
-                }
-                ++t;
-            }
-
-            PROF(frozen ? 5 : 6)
-            // ---------------- partial sums ----------------
-            if ((phi & 1) == 0) {
-                // left leaf: column 0 of C_n (size 1) lives at bit 1 of clsmall
-                if (active) clsmall = (clsmall & ~2ull) | ((u64)ubit << 1);
-            } else {
-                update_c(1, ubit, phi);
-            }
-            PROF(7)
+            // recursivelyCalcLLR for this leaf, then the leaf itself (fragments of this function body: the kernel is one function, its
+            // text is kept in three files)
+#include "polar_scl_visits.inc"
+#include "polar_scl_leaf.inc"
         }  // phi
         PROF_OUT
 
-        // ---------------- last (partial) history word ----------------
-        const int Wused = (int)((t + 31) >> 5);
-        if ((t & 31) != 0 && active) {
-            g_hist[(size_t)(Wused - 1) * CST + POLAR_CL] = hword;
-            g_horg[(size_t)(Wused - 1) * CST + POLAR_CL] = (uint32_t)origin;
-        }
-        wave_mem_fence();
-
-        // ---------------- findMostProbablePath + crc_check: PolarCode.cpp:609-644, 93-108 ----------------
-        // crc_check walks the path's word list backwards: parity of (word & mask_i) per CRC row
-        bool pass = true;
-        if (p.crc > 0) {
-            uint32_t acc = 0;
-            if (active) {
-                int cur = lig;
-                for (int w = Wused - 1; w >= 0; --w) {
-                    const uint32_t hw = g_hist[(size_t)w * CST + POLAR_CGB + cur];
-                    cur = (int)(g_horg[(size_t)w * CST + POLAR_CGB + cur] & (GS - 1));
-                    for (int i = 0; i < p.crc; ++i)
-                        acc ^= (uint32_t)(__popc(hw & p.crc_mask[(size_t)i * p.W + w]) & 1) << i;
-                }
-            }
-            pass = (acc == 0);
-        }
-        const u64 passm = (__ballot(active && pass) >> gbase) & gmask;
-        const bool cand = active && (pass || passm == 0);      // :640-643 fall back to "no CRC"
-        double key = (cand && pm < 1.7976931348623157e308) ? pm : __builtin_inf();
-        int kidx = lig;
-#pragma unroll
-        for (int off = GS / 2; off >= 1; off >>= 1) {
-            double ok = shfl_d(key, lane ^ off);
-            int oi = __shfl(kidx, lane ^ off, 64);
-            if (ok < key || (ok == key && oi < kidx)) { key = ok; kidx = oi; }
-        }
-        // no candidate with PM < DBL_MAX: the reference returns l_p = 0 (PolarCode.cpp:611,626)
-        const int win = (key < __builtin_inf()) ? kidx : 0;
-#ifdef POLAR_MARGIN
-        double fingap;
-        {   // final selection: runner-up candidate metric - winner's
-            const double mine = (cand && pm < 1.7976931348623157e308 && lig != win) ? pm : __builtin_inf();
-            fingap = group_reduce<GS, false>(mine, lane) - key;
-        }
-#endif
-        const double pm_win = shfl_d(pm, gbase + win);
-        // No candidate with a finite metric (every path met a frozen leaf with llr < -709.78: the reference's log(1+e^-llr)
-        // is +inf there) AND the list never filled (more list entries than 2^K paths): the reference's l_p = 0 is a path that
-        // was never activated, its info array still holds the zeros of initializeDataStructures (PolarCode.cpp:195-230).
-        // (Found by tools/fuzz_parity.py; this read used to return whatever an earlier codeword left in the slot.)
-        const bool win_active = __shfl((int)active, gbase + win, 64) != 0;
-        if (valid) {
-#if !defined(POLAR_PROFILE) && !defined(POLAR_SLOTHIST)
-            if (p.pm_out && lig == 0) p.pm_out[cw] = pm_win;
-#endif
-        }
-        {   // the winner's words, in order, into this lane's own column of g_tb (every lane of the group walks
-            // the same list, so the loads are broadcasts), then the K info bits by unfrozen rank
-            int cur = win;
-            for (int w = Wused - 1; w >= 0; --w) {
-                g_tb[(size_t)w * CST + POLAR_CL] = g_hist[(size_t)w * CST + POLAR_CGB + cur];
-                cur = (int)(g_horg[(size_t)w * CST + POLAR_CGB + cur] & (GS - 1));   // (stale slots of idle groups stay in range)
-            }
-            wave_mem_fence();
-        }
-        if (valid) {
-            for (int b = LAT ? lane : lig; b < K; b += LAT ? 64 : GS) {
-                unsigned r = p.info_rank[b];
-                uint32_t wd = g_tb[(size_t)(r >> 5) * CST + POLAR_CL];
-                p.out[(size_t)cw * K + b] = win_active ? (uint8_t)((wd >> (r & 31)) & 1u) : (uint8_t)0;
-            }
-        }
-        if constexpr (ED) {
-            // codewords with an undecidable |x| < 40 test go to the LLR-domain kernel (host: fallback pass)
-            guard |= __ballot(gacc <= ED_GACC_FLAG);
-            if constexpr (LAT) { if (valid && lane == 0) p.flags[cw] = (guard != 0) ? 1 : 0; }      // (no conversion pass has cleared it)
-            else if (valid && lig == 0 && ((guard >> gbase) & gmask) != 0) p.flags[cw] = 1;
-        }
-        wave_mem_fence();
-#ifdef POLAR_MARGIN
-        if (valid && lig == 0 && K >= 16) {      // (overwrites the first 16 info bytes: this build measures, it does not decode)
-            double *o = reinterpret_cast<double *>(p.out + (size_t)cw * K);
-            o[0] = mingap; o[1] = fingap;
-        }
-        wave_mem_fence();
-#endif
+#include "polar_scl_finish.inc"
         // next group
         if (p.work) {
             unsigned nxt = 0;
