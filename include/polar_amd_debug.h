@@ -18,7 +18,7 @@ extern "C" {
 /* polar_debug_set(h, key, value): negative return = error (unknown key, value out of range).
  * Measurement knobs (both libraries; results never depend on them):
  *   "mode_override" -1|0|1|2      replaces polar_set_mode's value (-1 = none); POLAR_MODE in the environment at creation
- *   "sc_no_fold", "no_tables", "no_rd1", "no_fuse_front", "no_prefix"     alternative (older) forms of single passes, for A/B timing
+ *   "sc_no_fold", "no_tables", "no_fuse_front", "no_prefix"     alternative (older) forms of single passes, for A/B timing
  *   "no_rccl", "force_rccl"       counter reduction of the single-process multi-device driver (drops its cached context)
  *   "lat_max_b"                   largest batch that takes the one-codeword-per-wave kernels (0 = default, -1 = never)
  *   "host_pipe_min_bytes", "host_chunk_bytes", "host_lanes", "host_threads", "host_ramp", "host_prefault"

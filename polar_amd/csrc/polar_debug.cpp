@@ -17,7 +17,6 @@ int polar_debug_set(polar_code_t *h, const char *key, long value) {
     else if (s == "sc_no_fold") k.sc_no_fold = value != 0;
     else if (s == "no_tables") k.no_tables = value != 0;
     else if (s == "no_fuse_front") k.no_fuse_front = value != 0;
-    else if (s == "no_rd1") k.no_rd1 = value != 0;
     else if (s == "no_prefix") h->prefix_on = (value == 0);          // (the all-frozen prefix decoded leaf by leaf by the list kernel itself)
     // (the cached streams / communicators / worker threads of the last device list were built under the old setting)
     else if (s == "no_rccl") { k.no_rccl = value != 0; multi_release(h, false); }

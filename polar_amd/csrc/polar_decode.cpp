@@ -112,7 +112,6 @@ int polar_host::decode_impl(polar_code *h, const void *d_llr, int llr_f32, long 
     p.pre = nullptr;
     p.flags = nullptr; p.cw_list = nullptr; p.cw_count = nullptr; p.n_dev = n_dev;
     p.tab_scr = nullptr; p.var_scr = nullptr;
-    p.rd1 = h->knobs.no_rd1 ? 0 : 1;
     if (p.prefix_q) {
         if ((rc = h->d_pre.ensure((size_t)B * (size_t)(h->N - p.prefix_q + 1)))) return rc;
         p.pre = h->d_pre.p;
@@ -307,7 +306,7 @@ int polar_decode_scl_p1_batch(polar_code_t *h, const double *p1, const double *p
     p.llr = h->d_in.p; p.llr_f32 = 0; p.p0 = h->d_in.p + (size_t)B * N; p.out = h->d_out.p; p.pm_out = nullptr;
     p.frozen = h->d_frozen.p; p.info_rank = h->d_info_rank.p; p.crc_mask = h->d_crc_mask.p; p.tabs = h->d_tabs.p;
     p.llr_scr = h->d_llr_scr.p; p.c_scr = h->d_c_scr.p; p.hist_scr = h->d_hist_scr.p;
-    p.flags = nullptr; p.cw_list = nullptr; p.cw_count = nullptr; p.n_dev = nullptr; p.tab_scr = nullptr; p.var_scr = nullptr; p.rd1 = 0;
+    p.flags = nullptr; p.cw_list = nullptr; p.cw_count = nullptr; p.n_dev = nullptr; p.tab_scr = nullptr; p.var_scr = nullptr;
     HIP_TRY(polar_launch_decode_p1(p, gs, grid, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, h->d_out.p, (size_t)B * h->K, hipMemcpyDeviceToHost));

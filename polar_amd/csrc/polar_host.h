@@ -259,7 +259,6 @@ struct polar_code {
         int mode_override = -1;      // POLAR_MODE=<0|1|2>: replaces `mode`
         bool sc_no_fold = false;     // POLAR_SC_NO_FOLD: list size 1 decodes a permuted, converted copy (front pass)
         bool no_tables = false;      // POLAR_NO_TABLES: list of 17..32 without the layer-1/2 value tables
-        bool no_rd1 = false;         // (hook) lane groups of 4 .. 16: layer 1 stored per path (the round-5 form) instead of re-derived
         bool no_fuse_front = false;  // (hook) exp-domain lists: separate conversion pass in front of the prefix kernel (the round-3 path)
         bool no_rccl = false;        // POLAR_NO_RCCL: multi-device counters summed on the host
         bool force_rccl = false;     // POLAR_FORCE_RCCL: RCCL even with one device

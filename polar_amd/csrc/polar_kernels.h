@@ -31,7 +31,6 @@ struct PolarDecodeParams {
     const unsigned int *n_dev;   // device: only the first min(B, *n_dev) codewords exist (Monte-Carlo alive lists), nullptr = B
     double *tab_scr;             // table mode (GS = 32, exp-domain): per-wave [grid][2][3N] layer-1/-2 value tables, nullptr = off
     uint32_t *var_scr;           //   per-wave [grid][N/32][64] variant nibbles of the paths
-    int rd1;                     // lane groups of 4 .. 16, exp-domain: layer 1 is re-derived from the channel row instead of stored (see scl_decode_llr_kernel)
 };
 
 size_t polar_decode_lds_bytes(int lds_log, int pipe);

@@ -158,13 +158,6 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     // layer 3 gather their inputs from the table. Two of the seven HBM-resident layers disappear.
     const int S1 = N / 2, S2 = N / 4;
     const bool tbl = ED && !PIPE && GS == 32 && N >= 1024 && p.tab_scr != nullptr && p.prefix_q > 0;
-    // ---- layer 1 re-derived (lane groups of 4, 8, 16; exp-domain; round 6): the values of layer 1 a path computes at phi = N/2
-    // (x1[e] = g(ch, ch', u1[e]), N/2 of them) have ONE later reader, the g-visit of layer 2 at phi = 3N/4. They are not stored:
-    // that visit computes them again from the codeword's channel row — 256 contiguous bytes per pass, shared by the paths of the
-    // group, instead of 16 rows per path — and the path's partial sums. 8 KiB written and 8 KiB read per path less, for N/2
-    // g-nodes per path more. (The list of 32 has its value tables instead; smaller groups amortise a table over too few paths.)
-    constexpr bool RD1 = ED && !PIPE && !LAT && GS >= 4 && GS <= 16;
-    const bool rd1 = RD1 && n >= 10 && p.rd1;
     double *tab_w = tbl ? p.tab_scr + (size_t)wave_id * G * (size_t)(3 * N) : nullptr;       // per codeword: X[N/2][2], T2[N/4][8]
     uint32_t *g_v = tbl ? p.var_scr + (size_t)wave_id * (size_t)(S2 / 8) * 64 : nullptr;     // V words [N/32][64]
 

@@ -170,6 +170,48 @@ def test_reference_design_point_statistics(built_lib):
     assert (np.abs(ref[diff] - thr) < 6 * np.sqrt(thr) + 10).all()
 
 
+TABLES = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "construction_tables.npz"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", [str(k) for k in TABLES["keys"]])
+def test_every_shipped_bicm_construction_table_is_reproduced_statistically(built_lib, key):
+    """Every Monte-Carlo construction table the reference ships for the BICM receiver (7 files: BPSK, 4- / 8- / 16-ASK Gray at
+    their design SNRs, 100 000 and 250 000 runs; tests/golden/construction_tables.npz, data only) against the device construction
+    at the same design point and run count. The reference drew its noise from MATLAB's generator, so the comparison is between
+    two independent samples of the same 1024 error probabilities (PolarCode.m:143-196 — parity of this row is UNPINNED by a
+    reference run; this is the tightest statement the image allows):
+      * every position within 6 sigma of the binomial difference;
+      * chi-square over the positions with at least 10 counts: chi2 / dof < 1.25 (dof ~ 600: that is + 4 sigma);
+      * Spearman rank correlation of the two tables > 0.999;
+      * totals within 0.3 %; the frozen sets differ only at positions whose count is within 6 sigma of the K-th smallest."""
+    import scipy.stats
+    import polar_amd
+    ref = TABLES[key + "/counts"].astype(np.float64)
+    snr, runs = float(TABLES[key + "/meta"][0]), int(TABLES[key + "/meta"][1])
+    const = key.split("_")[0]
+    got = polar_amd.mc_construction(10, snr, runs, const, seed=77).astype(np.float64)
+    tol = 6.0 * np.sqrt(ref + got + 1.0) + 3.0
+    bad = np.nonzero(np.abs(got - ref) > tol)[0]
+    assert bad.size == 0, (key, bad[:10], got[bad[:10]], ref[bad[:10]])
+    big = (ref + got) >= 20
+    chi2 = float((((got - ref) ** 2) / (got + ref))[big].sum())
+    assert big.sum() > 400 and chi2 / big.sum() < 1.25, (key, chi2, int(big.sum()))
+    rho = scipy.stats.spearmanr(got, ref).correlation
+    assert rho > 0.999, (key, rho)
+    assert abs(got.sum() - ref.sum()) < 3e-3 * ref.sum(), (key, got.sum(), ref.sum())
+    fr_ref = np.ones(1024, np.uint8)
+    fr_ref[np.argsort(ref, kind="stable")[:512]] = 0
+    with np.errstate(all="ignore"):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            code = polar_amd.PolarCode.from_counts(got, 512)
+    diff = np.nonzero(code.frozen_bits != fr_ref)[0]
+    thr = np.sort(ref)[511]
+    assert diff.size <= 24 and (np.abs(ref[diff] - thr) < 6 * np.sqrt(thr + 1) + 10).all(), (key, diff, thr)
+
+
 @pytest.mark.gpu
 def test_from_monte_carlo_builds_a_working_code(built_lib, tmp_path):
     """PolarCode.m:59-141 flow: construct, write the table in the reference's file format, reload it,

@@ -289,6 +289,61 @@ def test_decode_sc_p1_matches_oracle(built_lib, oracle_built):
     assert (got[10:] == g.decode_scl_llr(llr[10:], 1)).all()
 
 
+def _cpu_reference(n, K, crc, frozen=None, order=None):
+    """The unmodified reference build when it travelled with the snapshot (oracle/_ref), else the pinned restatement."""
+    import oracle_lib
+    cls = oracle_lib.Reference if oracle_lib.have_reference() else oracle_lib.Oracle
+    c = cls(n, K, 0.32, crc, srand=1)
+    if frozen is not None:
+        c.set_tables(frozen, order)
+    return c
+
+
+@pytest.mark.parametrize("ebno", [1.0, 2.5])
+def test_decode_sc_p1_equals_the_reference_decode_scl_llr_at_list_size_1(built_lib, oracle_built, ebno):
+    """SURVEY 8c cross-check for the PolarM-only row a18, against the REFERENCE itself (round 5 compared with this library's own
+    L = 1 decoder): PolarM's decode_sc_p1 on p1 = 1 / (1 + e^llr) returns, for every row that holds no exact tie, the bits
+    PolarC's decode_scl_llr(llr, 1) returns on llr — 4096 rows per SNR, decode failures included. (The probability-domain
+    recursion is another arithmetic than the LLR one: agreement is on DECISIONS; rows where the two CPU sides themselves
+    disagree — the restatement of decode_sc_p1 against the reference's LLR decoder — are counted and must be rare, and the
+    device must side with the decode_sc_p1 restatement there.)"""
+    o, g = _pair(10, 512, 0)
+    ref = _cpu_reference(10, 512, 0)
+    B = 4096
+    llr, _ = o.synth_llr(4242, 0, B, o.snr_sqrt_linear(ebno))
+    p1 = 1.0 / (1.0 + np.exp(llr))
+    got = g.decode_sc_p1(p1)
+    want = ref.decode_scl_llr(llr, 1)
+    differ = np.nonzero((got != want).any(axis=1))[0]
+    assert set(np.unique(got)) <= {0.0, 1.0}
+    assert differ.size <= 2, (ebno, differ[:10])                 # (a leaf within rounding of 0.5 may go either way: none seen)
+    for i in differ:
+        assert (got[i] == o.decode_sc_p1(p1[i])).all(), i
+    assert (got == want).all(axis=1).mean() > 0.999
+
+
+def test_decode_sc_p1_on_16ask_bicm_equals_the_reference_at_list_size_1(built_lib, oracle_built):
+    """The same cross-check on BASELINE configuration 5's own path (main_MC_CC_Comparison.m:90-96: the 16-ASK demapper's p1 goes
+    into decode_sc_p1): device BICM LLRs and p1 = 1 / (1 + e^llr) at two SNRs, the reference's shipped construction table;
+    device decode_sc_p1(p1) == unmodified PolarC decode_scl_llr(llr, 1), and device decode_scl_llr(llr, 8) == PolarC's at L = 8."""
+    import torch
+    import polar_amd
+    import golden_util as G
+    c, frozen, order, crcm = G.tables("cfg5_n10_k512_ask16")
+    g = polar_amd.PolarCode.from_tables(10, 512, 0, frozen, order)
+    ref = _cpu_reference(10, 512, 0, frozen, order)
+    for snr, B in ((11.0, 2048), (13.0, 2048)):
+        d = torch.empty((B, 1024), dtype=torch.float64, device="cuda")
+        g.synth_bicm_llr_dev("ask16-gray", 99, 0, B, snr, d.data_ptr())
+        torch.cuda.synchronize()
+        llr = d.cpu().numpy()
+        want1 = ref.decode_scl_llr(llr, 1)
+        got = g.decode_sc_p1(1.0 / (1.0 + np.exp(llr)))
+        assert ((got != want1).any(axis=1)).sum() <= 1, snr
+        assert (g.decode_scl_llr(llr, 1) == want1).all()
+        assert (g.decode_scl_llr(llr[:512], 8) == ref.decode_scl_llr(llr[:512], 8)).all()
+
+
 @pytest.mark.parametrize("n,K,crc", [(9, 256, 0), (10, 512, 8), (11, 1024, 16)])
 @pytest.mark.parametrize("L", [1, 4, 32])
 def test_winning_path_metric_matches_oracle(built_lib, oracle_built, n, K, crc, L):

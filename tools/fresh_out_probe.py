@@ -30,28 +30,7 @@ import torch
 import bench
 
 
-_libc = C.CDLL(None, use_errno=True)
-_libc.mmap.restype = C.c_void_p
-_libc.mmap.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_long]
-_libc.munmap.argtypes = [C.c_void_p, C.c_size_t]
-_libc.madvise.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
-
-
-class SmallPageBuffer:
-    """A fresh anonymous mapping with transparent huge pages switched OFF for it (MADV_NOHUGEPAGE): what a result array from
-    glibc malloc / a std::vector / MATLAB's allocator is on a system whose THP mode is `madvise` or `never` — numpy asks for
-    huge pages itself (its large arrays fault 512 times fewer pages and hide the effect)."""
-
-    def __init__(self, shape):
-        self.n = int(np.prod(shape))
-        self.p = _libc.mmap(None, self.n, 3, 0x22, -1, 0)           # PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS
-        assert self.p and self.p != C.c_void_p(-1).value
-        _libc.madvise(self.p, self.n, 15)                           # MADV_NOHUGEPAGE
-        self.a = np.ctypeslib.as_array((C.c_uint8 * self.n).from_address(self.p)).reshape(shape)
-
-    def close(self):
-        self.a = None
-        _libc.munmap(self.p, self.n)
+SmallPageBuffer = bench.SmallPageBuffer
 
 
 def med(f, reps, before=None, after=None):

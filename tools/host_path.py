@@ -54,7 +54,7 @@ def main():
         print(f"{c}: device-resident {rec['device_resident_cw_per_s'] / 1e6:.3f} M cw/s")
         for r in rec["rows"]:
             print(f"  {r['setting']:42s} {r['llr']} {r['value'] / 1e6:8.3f} M cw/s ({r['ms']:7.2f} ms, {r['input_GBps']:5.1f} GB/s in) bound {r['bound_cw_per_s'] / 1e6:7.3f} M ({r['bound_by']}) "
-                  f"-> {r['frac_of_bound']:5.2f}  chunks {r['chunks']} x {r['chunk_codewords']} lanes {r['lanes']} threads {r['copy_threads']} ok={r['bits_equal_device_resident']} fresh-out {r['fresh_out_value'] / 1e6:.3f} M us {r['host_thread_us']}", flush=True)
+                  f"-> {r['frac_of_bound']:5.2f}  chunks {r['chunks']} x {r['chunk_codewords']} lanes {r['lanes']} threads {r['copy_threads']} ok={r['bits_equal_device_resident']} reused-out {r['reused_out_value'] / 1e6:.3f} M us {r['host_thread_us']}", flush=True)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(res, open(a.out, "w"), indent=1)
 
