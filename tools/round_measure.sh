@@ -21,8 +21,10 @@ STRESS_SET=2 python tools/stress_parity.py 4 >> $O/stress_parity.txt 2>&1
 FUZZ_SANE=1 python tools/fuzz_parity.py 300 11 > $O/fuzz_sane.txt 2>&1
 python tools/fuzz_parity.py 150 12 > $O/fuzz_any.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 tools/mall_microbench.hip -o /tmp/mb 2>/dev/null && /tmp/mb > $O/cache_footprint_microbench.txt
-python tools/mc_rate.py 32 1048576 > $O/mc_rate.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 tools/traffic_replay.hip -o /tmp/tr 2>/dev/null && /tmp/tr 8 > $O/traffic_replay_raw.txt
+python tools/fresh_out_probe.py --out $O/fresh_out_probe.json > $O/fresh_out_probe.txt 2>&1
+bash tools/config_pmc.sh $O/pmc config3 config5 > /dev/null 2>&1
 python tools/sc_rounds.py $O/sc_rounds.json > $O/sc_rounds.txt 2>&1
 python tools/config4_record.py 100 8388608 > $O/config4_record.json 2>> $O/bench.err
 python tools/fuzz_parity_p1.py 60 > $O/fuzz_p1.txt 2>&1
-cat $O/gpu_tests.txt; tail -c 400 $O/bench_b524288.json; tail -2 $O/stress_parity.txt $O/fuzz_sane.txt $O/fuzz_any.txt $O/mc_rate.txt
+cat $O/gpu_tests.txt; tail -c 400 $O/bench_b524288.json; tail -2 $O/stress_parity.txt $O/fuzz_sane.txt $O/fuzz_any.txt
