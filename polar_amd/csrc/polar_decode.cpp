@@ -16,7 +16,9 @@ size_t scratch_budget(const polar_code *h) {
 // the persistent grid of the P1 kernels: `want` waves, each with `per_wave` bytes of scratch — halved until the scratch is there
 template <typename Ensure>
 int grid_that_fits(const polar_code *h, long want, size_t per_wave, Ensure ensure, int *grid_out) {
-    long grid = std::max<long>(1, std::min<long>(want, (long)(scratch_budget(h) / per_wave)));
+    // (the budget is a driver query — hipMemGetInfo takes milliseconds: asked only when the scratch the handle holds is too small)
+    long grid = want;
+    if ((size_t)want * per_wave > h->d_llr_scr.cap * sizeof(double)) grid = std::max<long>(1, std::min<long>(want, (long)(scratch_budget(h) / per_wave)));
     for (;;) {
         const int rc = ensure((int)grid);
         if (rc != POLAR_E_NOMEM || grid <= 64) { *grid_out = (int)grid; return rc; }
@@ -326,16 +328,26 @@ int polar_decode_sc_p1_batch(polar_code_t *h, const double *p1, long B, double *
     if (rc) return rc;
     const int N = h->N;
     if ((rc = h->d_in.ensure((size_t)B * N + (size_t)B * h->K))) return rc;
-    int grid = 1;
-    rc = grid_that_fits(h, std::min<long>((B + 63) / 64, (long)h->num_cu * 16), (size_t)N * 64 * 4 * sizeof(double),
-                        [&](int g) { return h->d_llr_scr.ensure((size_t)g * 4 * N * 64 + 64); }, &grid);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(h->d_in.p, p1, (size_t)B * N * sizeof(double), hipMemcpyHostToDevice));
     PolarScP1Params p;
     p.n = h->n; p.N = N; p.K = h->K; p.B = B;
     p.p1 = h->d_in.p; p.out = h->d_in.p + (size_t)B * N;
-    p.frozen = h->d_frozen.p; p.order = h->d_order.p; p.scr = h->d_llr_scr.p;
-    HIP_TRY(polar_launch_sc_p1(p, grid, nullptr));
+    p.frozen = h->d_frozen.p; p.order = h->d_order.p; p.scr = nullptr;
+    HIP_TRY(hipMemcpy(h->d_in.p, p1, (size_t)B * N * sizeof(double), hipMemcpyHostToDevice));
+    // Small batches (PolarM calls this once per codeword, main_MC_CC_Comparison.m:96): one codeword per WAVE, state in LDS; from
+    // about one codeword per lane of the waves the device holds the lane-per-codeword kernel wins (its 64 codewords per wave
+    // share every instruction). Same doubles either way.
+    const long lat_waves = polar_sc_p1_lat_lds_bytes(N) <= h->lds_per_block ? (long)h->num_cu * std::max<long>(1, (long)(h->lds_per_block / polar_sc_p1_lat_lds_bytes(N))) : 0;
+    const long lat_max = h->knobs.lat_max_b < 0 ? 0 : (h->knobs.lat_max_b ? h->knobs.lat_max_b : lat_waves * 4);
+    if (lat_waves > 0 && B <= lat_max) {
+        HIP_TRY(polar_launch_sc_p1_lat(p, (int)std::min<long>(B, lat_waves), nullptr));
+    } else {
+        int grid = 1;
+        rc = grid_that_fits(h, std::min<long>((B + 63) / 64, (long)h->num_cu * 16), (size_t)N * 64 * 4 * sizeof(double),
+                            [&](int g) { return h->d_llr_scr.ensure((size_t)g * 4 * N * 64 + 64); }, &grid);
+        if (rc) return rc;
+        p.scr = h->d_llr_scr.p;
+        HIP_TRY(polar_launch_sc_p1(p, grid, nullptr));
+    }
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, p.out, (size_t)B * h->K * sizeof(double), hipMemcpyDeviceToHost));
     return POLAR_OK;

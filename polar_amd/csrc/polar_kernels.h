@@ -60,6 +60,9 @@ struct PolarScP1Params {
     double *scr;                 // per-wave scratch [grid][4*N][64]
 };
 hipError_t polar_launch_sc_p1(const PolarScP1Params &p, int grid, hipStream_t st);
+// small batches: one codeword per wave, state in LDS (polar_sc_p1_lat_lds_bytes(N) must fit the device's LDS)
+hipError_t polar_launch_sc_p1_lat(const PolarScP1Params &p, int grid, hipStream_t st);
+size_t polar_sc_p1_lat_lds_bytes(int N);
 
 // list size 1: pruned successive cancellation (polar_kernels_sc.hip)
 struct PolarScParams {

@@ -356,6 +356,82 @@ __global__ __launch_bounds__(64) void sc_p1_kernel(PolarScP1Params p) {
     }
 }
 
+// ---- the same decoder for SMALL batches: ONE codeword per wave, the elements of a layer spread over the 64 lanes, the whole
+// state in LDS (round 6). PolarM's loop calls decode_sc_p1 once per codeword (main_MC_CC_Comparison.m:96): with one LANE per
+// codeword a single call is 22 528 node evaluations in a row, each behind a round trip to the HBM scratch (7.6 ms at N = 2048).
+// Same expressions per node, same element order, no reductions: the doubles are those of sc_p1_kernel bit for bit.
+// LDS: y layers (size S at offset S: N doubles), xl / xr (N each), u (N): 4 N doubles = 64 KiB at N = 2048.
+__global__ __launch_bounds__(64) void sc_p1_lat_kernel(PolarScP1Params p) {
+    extern __shared__ double lds_p1[];
+    const int lane = threadIdx.x;
+    const int n = p.n, N = p.N, K = p.K;
+    double *ly = lds_p1, *lxl = ly + N, *lxr = lxl + N, *lu = lxr + N;
+    for (long cw = blockIdx.x; cw < p.B; cw += gridDim.x) {
+        const double *y0 = p.p1 + (size_t)cw * N;
+        for (int phi = 0; phi < N; ++phi) {
+            const int lam_top = phi ? (n - __builtin_ctz((unsigned)phi)) : 1;
+            for (int lam = lam_top; lam <= n; ++lam) {
+                const int sh = n - lam, S = 1 << sh;
+                const bool odd = (phi >> sh) & 1;
+                for (int j = lane; j < S; j += 64) {
+                    double a, b;
+                    if (lam == 1) {
+                        const unsigned idx = __brev((unsigned)j) >> (32 - n);
+                        a = y0[idx]; b = y0[idx + 1];
+                    } else {
+                        a = ly[2 * S + j]; b = ly[2 * S + j + S];
+                    }
+                    double r;
+                    if (!odd) r = a * (1 - b) + b * (1 - a);                       // cnop, PolarCode.m:889-891
+                    else {
+                        const double x = lxl[S + j];
+                        const double w1 = x * (1 - a) + a * (1 - x);                // cnop(u1hardprev, y_odd)
+                        r = w1 * b / (w1 * b + (1 - w1) * (1 - b));                 // vnop, :893-895
+                    }
+                    ly[S + j] = r;
+                }
+                wave_mem_fence();
+            }
+            const double leaf = ly[1];
+            double x;
+            if (p.frozen[phi]) x = 0.0;                                              // :875-876
+            else { const double tt = 1 - 2 * leaf; x = (1 - (double)((tt > 0) - (tt < 0))) / 2; }   // :873
+            if (lane == 0) {
+                lu[phi] = x;
+                if ((phi & 1) == 0) lxl[1] = x; else lxr[1] = x;
+            }
+            wave_mem_fence();
+            if (phi & 1) {
+                int S = 1, ph = phi;
+                for (;;) {
+                    if (4 * S > N) break;
+                    const int psi = ph >> 1;
+                    const bool to_right = psi & 1;
+                    double *dst = (to_right ? lxr : lxl) + 2 * S;
+                    for (int j = lane; j < S; j += 64) {
+                        const double x1 = lxl[S + j], x2 = lxr[S + j];
+                        dst[j] = x1 * (1 - x2) + x2 * (1 - x1);                         // cnop(u1hard, u2hard) :885
+                        dst[j + S] = x2;
+                    }
+                    wave_mem_fence();
+                    if (!to_right) break;
+                    S *= 2; ph = psi;
+                }
+            }
+        }
+        for (int b = lane; b < K; b += 64) p.out[(size_t)cw * K + b] = lu[p.order[b]];
+        wave_mem_fence();
+    }
+}
+size_t polar_sc_p1_lat_lds_bytes(int N) { return (size_t)4 * N * sizeof(double); }
+hipError_t polar_launch_sc_p1_lat(const PolarScP1Params &p, int grid, hipStream_t st) {
+    const size_t lds = polar_sc_p1_lat_lds_bytes(p.N);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sc_p1_lat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sc_p1_lat_kernel, dim3(grid), dim3(64), lds, st, p);
+    return hipGetLastError();
+}
+
 hipError_t polar_launch_decode_p1(const PolarDecodeParams &p, int gs, int grid, hipStream_t st) {
     switch (gs) {
         case 1: hipLaunchKernelGGL(scl_decode_p1_kernel<1>, dim3(grid), dim3(64), 0, st, p); break;
