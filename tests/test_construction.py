@@ -183,8 +183,8 @@ def test_every_shipped_bicm_construction_table_is_reproduced_statistically(built
     reference run; this is the tightest statement the image allows):
       * every position within 6 sigma of the binomial difference;
       * chi-square over the positions with at least 10 counts: chi2 / dof < 1.25 (dof ~ 600: that is + 4 sigma);
-      * Spearman rank correlation of the two tables > 0.995 over those positions (> 0.97 over all 1024, where the many
-        zero and near-zero counts are ties and noise);
+      * linear correlation of the two count tables > 0.9999, Spearman rank correlation > 0.97 (measured 0.98-0.99: ~ 40 % of
+        the positions are zero or near-zero counts, and the bad end has equal probabilities — ties and noise in the ranks);
       * totals within 0.3 %; the frozen sets differ only at positions whose count is within 6 sigma of the K-th smallest."""
     import scipy.stats
     import polar_amd
@@ -199,8 +199,10 @@ def test_every_shipped_bicm_construction_table_is_reproduced_statistically(built
     chi2 = float((((got - ref)[big] ** 2) / (got + ref)[big]).sum())
     assert big.sum() > 400 and chi2 / big.sum() < 1.25, (key, chi2, int(big.sum()))
     # (over all 1024 positions ~ 40 % are zero or near-zero counts whose ranks are ties and noise: measured 0.98-0.99)
-    rho, rho_big = scipy.stats.spearmanr(got, ref).correlation, scipy.stats.spearmanr(got[big], ref[big]).correlation
-    assert rho > 0.97 and rho_big > 0.995, (key, rho, rho_big)
+    # (many positions have equal error probabilities — 0.5 at the bad end — whose ranks are noise as well: the rank statistic is a
+    # coarse check, the linear correlation of the counts the sharp one)
+    rho, r = scipy.stats.spearmanr(got, ref).correlation, np.corrcoef(got, ref)[0, 1]
+    assert rho > 0.97 and r > 0.9999, (key, rho, r)
     assert abs(got.sum() - ref.sum()) < 3e-3 * ref.sum(), (key, got.sum(), ref.sum())
     fr_ref = np.ones(1024, np.uint8)
     fr_ref[np.argsort(ref, kind="stable")[:512]] = 0
