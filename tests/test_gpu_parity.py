@@ -282,7 +282,7 @@ def test_decode_sc_p1_matches_oracle(built_lib, oracle_built):
     p1 = 1.0 / (1.0 + np.exp(llr))
     p1[3, ::7] = 0.5
     p1[4, :] = 0.5
-    got = G.both_kernels(g, lambda: g.decode_sc_p1(p1))        # one lane per codeword / one codeword per wave (round 6): the same doubles
+    got = both_kernels(g, lambda: g.decode_sc_p1(p1))        # one lane per codeword / one codeword per wave (round 6): the same doubles
     for i in range(p1.shape[0]):
         assert (got[i] == o.decode_sc_p1(p1[i])).all(), i
     # agrees with the LLR decoder at L = 1 on ordinary inputs (SURVEY 8c cross-check)
