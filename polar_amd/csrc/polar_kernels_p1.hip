@@ -9,6 +9,7 @@
 // -ffp-contract=off is required (the reference's products and sums are separately rounded).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "polar_kernels.h"
 #include "polar_device.h"
@@ -62,56 +63,89 @@ __global__ __launch_bounds__(64) void scl_decode_p1_kernel(PolarDecodeParams p) 
                 const bool odd = (phi >> sh) & 1;
                 double sig = 0.0;
                 double2 *outp = g_p + (size_t)S * 64 + lane;
-                if (active) {
-                    const int pin = (lam > 1) ? pL.get(sh + 1) : 0;
-                    const double2 *inp = g_p + (size_t)(2 * S) * 64 + gbase + pin;
-                    uint32_t cbits = 0;
-                    const uint32_t *cwp = nullptr;
-                    if (odd) {
-                        if (S <= 32) cbits = (uint32_t)(clsmall >> S);
-                        else cwp = g_cl + (size_t)(S / 32 - 2) * 64 + gbase + pC.get(sh);
-                    }
-                    for (int j = 0; j < S; ++j) {
-                        double a0, a1, b0, b1;
-                        if (lam == 1) {
-                            unsigned idx = __brev((unsigned)j) >> (32 - n);
-                            a0 = in_p0[idx]; a1 = in_p1[idx]; b0 = in_p0[idx + 1]; b1 = in_p1[idx + 1];
-                        } else {
-                            double2 a = inp[(size_t)j * 64], b = inp[(size_t)(j + S) * 64];
-                            a0 = a.x; a1 = a.y; b0 = b.x; b1 = b.y;
+                // Round 6: U elements per pass with all their loads issued before the first use (the element-by-element loop paid a
+                // memory round trip per element), and layers of size <= 8 are normalised in registers and written ONCE (they were
+                // written, fenced, re-read, divided and written again). Same operations on the same operands: max is
+                // order-independent, every product, sum and quotient is the one the loop computed.
+                auto visit = [&](auto UU) {
+                    constexpr int U = decltype(UU)::value;
+                    const bool in_regs = (S <= U);                 // the whole layer is this one pass
+                    double r0[U], r1[U];
+                    if (active) {
+                        const int pin = (lam > 1) ? pL.get(sh + 1) : 0;
+                        const double2 *inp = g_p + (size_t)(2 * S) * 64 + gbase + pin;
+                        uint32_t cbits = 0;
+                        const uint32_t *cwp = nullptr;
+                        if (odd) {
+                            if (S <= 32) cbits = (uint32_t)(clsmall >> S);
+                            else cwp = g_cl + (size_t)(S / 32 - 2) * 64 + gbase + pC.get(sh);
                         }
-                        double o0, o1;
-                        if (!odd) {                                   // :392-395
-                            o0 = 0.5 * (a0 * b0 + a1 * b1);
-                            o1 = 0.5 * (a1 * b0 + a0 * b1);
-                        } else {                                      // :398-400
-                            if (S > 32 && (j & 31) == 0) cbits = cwp[(size_t)(j >> 5) * 64];
-                            const unsigned u = (cbits >> (j & 31)) & 1u;
-                            o0 = (0.5 * (u ? a1 : a0)) * b0;
-                            o1 = (0.5 * (u ? a0 : a1)) * b1;
+                        for (int j0 = 0; j0 < S; j0 += U) {
+                            double a0[U], a1[U], b0[U], b1[U];
+#pragma unroll
+                            for (int k = 0; k < U; ++k) {
+                                const int j = j0 + k;
+                                if (lam == 1) {
+                                    const unsigned idx = __brev((unsigned)j) >> (32 - n);
+                                    a0[k] = in_p0[idx]; a1[k] = in_p1[idx]; b0[k] = in_p0[idx + 1]; b1[k] = in_p1[idx + 1];
+                                } else {
+                                    const double2 a = inp[(size_t)j * 64], b = inp[(size_t)(j + S) * 64];
+                                    a0[k] = a.x; a1[k] = a.y; b0[k] = b.x; b1[k] = b.y;
+                                }
+                            }
+                            if (odd && S > 32 && (j0 & 31) == 0) cbits = cwp[(size_t)(j0 >> 5) * 64];
+#pragma unroll
+                            for (int k = 0; k < U; ++k) {
+                                const int j = j0 + k;
+                                double o0, o1;
+                                if (!odd) {                                   // :392-395
+                                    o0 = 0.5 * (a0[k] * b0[k] + a1[k] * b1[k]);
+                                    o1 = 0.5 * (a1[k] * b0[k] + a0[k] * b1[k]);
+                                } else {                                      // :398-400
+                                    const unsigned u = (cbits >> (j & 31)) & 1u;
+                                    o0 = (0.5 * (u ? a1[k] : a0[k])) * b0[k];
+                                    o1 = (0.5 * (u ? a0[k] : a1[k])) * b1[k];
+                                }
+                                sig = (sig < o0) ? o0 : sig;                  // :402-403
+                                sig = (sig < o1) ? o1 : sig;
+                                r0[k] = o0; r1[k] = o1;
+                            }
+                            if (!in_regs) {
+#pragma unroll
+                                for (int k = 0; k < U; ++k) outp[(size_t)(j0 + k) * 64] = make_double2(r0[k], r1[k]);
+                            }
                         }
-                        sig = (sig < o0) ? o0 : sig;                  // :402-403
-                        sig = (sig < o1) ? o1 : sig;
-                        outp[(size_t)j * 64] = make_double2(o0, o1);
+                        pL.set(sh, lig);
                     }
-                    pL.set(sh, lig);
-                }
-                // sigma over ALL active paths of the codeword, then normalise (:409-419)
-                sig = group_reduce<GS, true>(sig, lane);
-                wave_mem_fence();
-                if (active && sig != 0) {
-                    for (int j = 0; j < S; ++j) {
-                        double2 v = outp[(size_t)j * 64];
-                        v.x = v.x / sig;
-                        v.y = v.y / sig;
-                        outp[(size_t)j * 64] = v;
-                        lp0 = v.x; lp1 = v.y;      // S == 1 at the last layer: the leaf pair
+                    // sigma over ALL active paths of the codeword, then normalise (:409-419)
+                    sig = group_reduce<GS, true>(sig, lane);
+                    if (in_regs) {
+                        if (active) {
+#pragma unroll
+                            for (int k = 0; k < U; ++k) {
+                                if (sig != 0) { r0[k] = r0[k] / sig; r1[k] = r1[k] / sig; }
+                                outp[(size_t)k * 64] = make_double2(r0[k], r1[k]);
+                            }
+                            lp0 = r0[0]; lp1 = r1[0];             // S == 1 at the last layer: the leaf pair
+                        }
+                    } else {
+                        wave_mem_fence();
+                        if (active && sig != 0) {
+                            for (int j0 = 0; j0 < S; j0 += U) {
+                                double2 v[U];
+#pragma unroll
+                                for (int k = 0; k < U; ++k) v[k] = outp[(size_t)(j0 + k) * 64];
+#pragma unroll
+                                for (int k = 0; k < U; ++k) { v[k].x = v[k].x / sig; v[k].y = v[k].y / sig; outp[(size_t)(j0 + k) * 64] = v[k]; }
+                            }
+                        }
                     }
-                } else if (active && S == 1) {
-                    double2 v = outp[0];
-                    lp0 = v.x; lp1 = v.y;
-                }
-                wave_mem_fence();
+                    wave_mem_fence();
+                };
+                if (S == 1) visit(std::integral_constant<int, 1>{});
+                else if (S == 2) visit(std::integral_constant<int, 2>{});
+                else if (S == 4) visit(std::integral_constant<int, 4>{});
+                else visit(std::integral_constant<int, 8>{});
             }
 
             const bool frozen = p.frozen[phi] != 0;
@@ -125,7 +159,22 @@ __global__ __launch_bounds__(64) void scl_decode_p1_kernel(PolarDecodeParams p) 
                 const int rho = (2 * nact < L) ? 2 * nact : L;
                 bool c0 = active, c1 = active;
                 const bool need = (2 * nact > L);
-                if (__any(need)) {
+                // Exact fast path (round 6; the LLR kernel's, in the probability domain): the list is full and every path's better
+                // fork strictly beats every path's worse fork => the L survivors are the L better forks in whatever order they
+                // rank: nobody is killed or cloned and the 2 L-entry ranking loop (half of this kernel's time at L = 32) is
+                // skipped. A tie anywhere (pf0 == pf1 in a path, or a better fork equal to some worse fork) fails the strict test
+                // and takes the ranking below, where the reference's index order decides.
+                bool fastp;
+                {
+                    const double gd = active ? ((pf0 > pf1) ? pf0 : pf1) : __builtin_inf();
+                    const double bd = active ? ((pf0 > pf1) ? pf1 : pf0) : -__builtin_inf();
+                    const double gmin = group_reduce<GS, false>(gd, lane), bmax = group_reduce<GS, true>(bd, lane);
+                    fastp = __all((nact == 0) || (nact == L && gmin > bmax));
+                }
+                if (fastp) {
+                    c0 = active && (pf0 > pf1);
+                    c1 = active && !c0;
+                } else if (__any(need)) {
                     sortbuf[2 * lane] = pf0;
                     sortbuf[2 * lane + 1] = pf1;
                     wave_mem_fence();
