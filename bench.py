@@ -298,11 +298,15 @@ def main():
                                   "distinct_devices": len(set(gather_device_ids(dist, local_rank, shared))),
                                   "native_multi_used_rccl": res.get("monte_carlo", {}).get("native_multi", {}).get("used_rccl")}
     hung = bool(res.get("monte_carlo", {}).get("native_multi_hung"))
+    res["section_seconds"] = {}
+
     def guarded(name, fn):
         """The records beside the headline must not be able to take the result line with them: a failure in one of them is
         recorded in its place."""
+        t_sec = time.perf_counter()
         try:
             res[name] = fn()
+            res["section_seconds"][name] = round(time.perf_counter() - t_sec, 1)
         except Exception as ex:
             import traceback
             res[name] = {"error": f"{type(ex).__name__}: {ex}"[:500], "traceback_tail": traceback.format_exc()[-800:]}
@@ -807,13 +811,14 @@ class SmallPageBuffer:
         self._L.munmap(self.p, self.n)
 
 
-def host_batch_config(name, B, dev, pcie, settings=(("default", {}),), reps=5, seed=7):
+def host_batch_config(name, B, dev, pcie, settings=(("default", {}),), reps=3, seed=7):
     """One configuration through the HOST-POINTER batch entry points (polar_decode_scl_llr_batch / _f32 — the only path a MEX or
     PolarCode.hpp caller has: PolarCode.cpp:130-148, PolarM/PolarCode.m:312-322) from PAGEABLE numpy memory: codewords/s
     including staging, H2D, decode, D2H, next to the device-resident rate of the same batch and the bound
     min(device-resident rate, pinned PCIe rate / input bytes per codeword); bits compared with the device-resident decode."""
     import ctypes as C
     import polar_amd
+    t_cfg = time.perf_counter()
     if name == "headline":
         n, K, crc, L, axis, const = 11, 1024, 16, 32, 2.0, "bpsk"
         C.CDLL(None).srand(C.c_uint(1))
@@ -854,7 +859,7 @@ def host_batch_config(name, B, dev, pcie, settings=(("default", {}),), reps=5, s
         for dt_name, a, w in (("f64", llr64, want), ("f32", llr32, want32)):
             got = code.decode_scl_llr(a, L)           # warm-up: staging slots, decode lanes
             ok = bool((got == w).all())
-            for _ in range(10):                       # (a setter has just dropped the extra decode lanes: the first calls after it
+            for _ in range(6):                        # (a setter has just dropped the extra decode lanes: the first calls after it
                 code.decode_scl_llr(a, L, out=got)    # rebuild them and run on freshly allocated device scratch — slower for ~0.2 s)
             # `value` is what a MEX gateway / std::vector caller sees: a NEW result buffer per call, small pages, never touched
             # (allocated before the clock, released after it: the library call alone). Beside it the rate with one result array
@@ -884,8 +889,10 @@ def host_batch_config(name, B, dev, pcie, settings=(("default", {}),), reps=5, s
                                 "bits_equal_device_resident": ok, "chunks": code.debug_get("host_chunks"),
                                 "chunk_codewords": code.debug_get("host_chunk_cw"), "lanes": code.debug_get("host_lanes"),
                                 "copy_threads": code.debug_get("host_threads")})
+    rec["seconds_c_abi_rows"] = round(time.perf_counter() - t_cfg, 1)
     if len(settings) == 1:
         rec["mex_gateway"] = mex_gateway_rows(code, llr64, llr32, want, want32, L, B, N, K, reps)
+    rec["seconds"] = round(time.perf_counter() - t_cfg, 1)
     for k in HOST_KNOBS:
         code.debug_set(k, 0)
     code.close()
@@ -910,9 +917,9 @@ def mex_gateway_rows(code, llr64, llr32, want, want32, L, B, N, K, reps):
         for dt_name, a, w in (("f64", llr64, want), ("f32", llr32, want32)):
             cols = a.T                                   # N x B view; the driver stores it column-major = the rows of `a`
             ts, ok = [], True
-            for i in range(reps + 3):
+            for i in range(4):                           # (every call copies the batch into an mxArray first: three timed calls are enough)
                 u = mex('decode_scl_llr', h, cols, float(L))
-                if i >= 3:
+                if i >= 1:
                     ts.append(mex.last_call_seconds)
                 ok = ok and u.shape == (K, B) and bool((u.T == w).all())
             rows.append({"llr": dt_name, "layout": "N x B", "value": B / min(ts), "unit": "codewords/s", "median": B / float(np.median(ts)),
