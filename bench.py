@@ -915,13 +915,14 @@ def mex_gateway_rows(code, llr64, llr32, want, want32, L, B, N, K, reps):
     rows = []
     try:
         for dt_name, a, w in (("f64", llr64, want), ("f32", llr32, want32)):
-            cols = a.T                                   # N x B view; the driver stores it column-major = the rows of `a`
+            cols = mex.value(a.T)                        # N x B: stored column-major = the rows of `a`; a workspace variable, converted once
             ts, ok = [], True
-            for i in range(4):                           # (every call copies the batch into an mxArray first: three timed calls are enough)
+            for i in range(4):
                 u = mex('decode_scl_llr', h, cols, float(L))
                 if i >= 1:
                     ts.append(mex.last_call_seconds)
                 ok = ok and u.shape == (K, B) and bool((u.T == w).all())
+            cols.free()
             rows.append({"llr": dt_name, "layout": "N x B", "value": B / min(ts), "unit": "codewords/s", "median": B / float(np.median(ts)),
                          "ms_in_mexFunction": min(ts) * 1e3, "bits_equal_device_resident": ok})
     finally:

@@ -48,6 +48,19 @@ def build(force=False):
     return SO
 
 
+class MxValue:
+    """An argument converted once (Mex.value) and passed to several calls: a MATLAB variable that lives in the workspace while a
+    script calls the MEX file repeatedly. Freed by .free()."""
+
+    def __init__(self, mex, ptr):
+        self.mex, self.ptr = mex, ptr
+
+    def free(self):
+        if self.ptr:
+            self.mex.L.fm_free(self.ptr)
+            self.ptr = None
+
+
 class Mex:
     """``polar_mex = Mex(); out = polar_mex('cmd', args..., nlhs=k)``: one MEX file loaded into this process."""
 
@@ -72,7 +85,12 @@ class Mex:
         self.L = L
 
     # ---- MATLAB value -> mxArray --------------------------------------------------------------------------------------
+    def value(self, v):
+        return MxValue(self, self._to_mx(v))
+
     def _to_mx(self, v):
+        if isinstance(v, MxValue):
+            return v.ptr
         if isinstance(v, str):
             return self.L.fm_string(v.encode())
         if isinstance(v, (bool, int, float, np.integer, np.floating)) and not isinstance(v, np.generic):
@@ -103,6 +121,7 @@ class Mex:
     def __call__(self, cmd, *args, nlhs=1):
         import time
         prhs = [self._to_mx(cmd)] + [self._to_mx(a) for a in args]
+        owned = [p for p, a in zip(prhs, (cmd,) + args) if not isinstance(a, MxValue)]
         arr = (C.c_void_p * len(prhs))(*prhs)
         out = (C.c_void_p * max(nlhs, 1))()
         eid, emsg = C.create_string_buffer(256), C.create_string_buffer(1024)
@@ -119,7 +138,7 @@ class Mex:
                 res.append(self._from_mx(out[i]))
             return res[0] if nlhs == 1 else tuple(res) if nlhs else None
         finally:
-            for p in prhs:
+            for p in owned:
                 self.L.fm_free(p)
             for i in range(nlhs):
                 if out[i]:
