@@ -116,7 +116,7 @@ class Mex:
         if m * n == 0:
             return np.zeros((m, n), dt)
         buf = (C.c_char * (m * n * dt.itemsize)).from_address(self.L.fm_data(p))
-        return np.frombuffer(buf, dt).reshape((m, n), order="F").copy()
+        return np.frombuffer(buf, dt).reshape((m, n), order="F").copy(order="F")      # (MATLAB arrays stay column-major)
 
     def __call__(self, cmd, *args, nlhs=1):
         import time
