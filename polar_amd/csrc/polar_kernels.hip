@@ -74,7 +74,7 @@ __device__ __forceinline__ const double *ch_row(const PolarDecodeParams &p, size
 #endif
 // per-phase re-derivation of the lane-dependent invariants (see lane_id_opaque in polar_device.h)
 #define LANE_CTX                                   \
-    const int lane = lane_id_opaque();             \
+    const int lane = LAT ? lane_k : lane_id_opaque();   /* (LAT: 135 of 256 registers in use — nothing to keep short-lived) */ \
     const int lig = lane & (GS - 1);               \
     const int gbase = lane & ~(GS - 1);            \
     (void)lig; (void)gbase;
@@ -106,6 +106,8 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave in block (uniform: keeps every per-wave base pointer in SGPRs)
     const int wave_id = blockIdx.x * WPB + wib;             // owns one slice of the global scratch
     const int nwaves = gridDim.x * WPB;
+    const int lane_k = lane;           // (the name the LAT code uses where LANE_CTX shadows `lane`)
+    (void)lane_k;
     const int lig = lane & (GS - 1);   // path index l of the reference
     const int gbase = lane & ~(GS - 1);
     const int grp = LAT ? 0 : lane / GS;
@@ -252,7 +254,24 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         // trip on the critical path of every leaf
         typedef const uint32_t __attribute__((address_space(4))) *kconst_u32;
         const kconst_u32 ctlp = (kconst_u32)(uintptr_t)p.ctl;
-        uint32_t ctl_next = ctlp[phi_start];
+        // LAT (round 6): a lone wave cannot hide the scalar load — it shares lgkmcnt with the LDS operations, so the first LDS wait of
+        // every leaf step also waited for the control word of the NEXT one (a constant-cache miss every 16 leaves: ~1 us). The control
+        // words of 64 leaves ride in one VGPR (lane i: leaf window + i), loaded one window ahead by a vector load (vmcnt: nothing
+        // in the leaf loop waits on it); a leaf's word is one v_readlane.
+        uint32_t ctlv = 0, ctlv_n = 0;
+        // (LAT, round 6) the two lowest layers are not stored: the four values of the layer of size 4 a path's current quad of leaves hangs
+        // off (lat_x, read once per quad) and the two of the layer of size 2 (lat_y) ride in registers, replicated in the lanes of the
+        // path like the rest of its state and copied with it by a clone (polar_scl_visits.inc, polar_scl_leaf.inc)
+        double lat_x[4] = {0.0, 0.0, 0.0, 0.0}, lat_y0 = 0.0, lat_y1 = 0.0;
+        bool lat_xv = false, lat_yv = false;        // valid (wave-uniform)
+        (void)lat_x; (void)lat_y0; (void)lat_y1; (void)lat_xv; (void)lat_yv;
+        auto ctl_window = [&](int w0) -> uint32_t { const int i_ = w0 + lane_id_opaque(); return p.ctl[i_ < N ? i_ : 0]; };
+        uint32_t ctl_next;
+        if constexpr (LAT) {
+            ctlv = ctl_window(phi_start & ~63);
+            ctlv_n = ctl_window((phi_start & ~63) + 64);
+            ctl_next = (uint32_t)__builtin_amdgcn_readlane((int)ctlv, phi_start & 63);
+        } else ctl_next = ctlp[phi_start];
         for (int phi = phi_start; phi < N; ++phi) {
             PROF(0)
             const uint32_t ctl = ctl_next;
@@ -260,6 +279,34 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
             // that layer (the S bits just completed by a RIGHT child with node index ph)
             auto update_c = [&](int S, uint32_t X, int ph) {
                 LANE_CTX
+                if constexpr (LAT) {
+                    // (round 6) after a right LEAF: the levels S = 1 ... 16 live in the register word and are walked with constant
+                    // shifts on its 32-bit halves — the generic loop below shifts a 64-bit word by a variable amount at every
+                    // level (a dozen instructions of a lone wave's issue slots each); from the layer of 32 on it takes over
+                    if (S == 1 && N >= 128) {
+                        uint32_t lo = (uint32_t)clsmall, hi = (uint32_t)(clsmall >> 32);
+                        bool done = false;
+                        auto level = [&](auto SC_) {
+                            constexpr int Sc = decltype(SC_)::value;
+                            if (done) return;
+                            const uint32_t cl = (Sc == 16) ? (lo >> 16) : ((lo >> Sc) & ((1u << Sc) - 1u));
+                            const uint32_t nw = (cl ^ X) | (X << Sc);
+                            if (!((ph >> 1) & 1)) {
+                                if constexpr (Sc == 16) hi = nw;
+                                else if constexpr (Sc == 8) lo = (lo & 0x0000FFFFu) | (nw << 16);
+                                else lo = (lo & ~(((1u << (2 * Sc)) - 1u) << (2 * Sc))) | (nw << (2 * Sc));
+                                done = true;
+                            } else { X = nw; ph >>= 1; }
+                        };
+                        level(std::integral_constant<int, 1>{}); level(std::integral_constant<int, 2>{}); level(std::integral_constant<int, 4>{});
+                        level(std::integral_constant<int, 8>{}); level(std::integral_constant<int, 16>{});
+                        if (done) {
+                            if (active) clsmall = ((u64)hi << 32) | lo;
+                            return;
+                        }
+                        S = 32;               // (nothing was written: every level so far was a right child)
+                    }
+                }
                 for (;;) {
                     if (4 * S > N) break;                   // C_0 is never read (PolarCode.cpp writes it, nobody uses it)
                     const int psi = ph >> 1;
@@ -313,7 +360,10 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
             const int zb = (int)(ctl >> 1) & 0x7F;
             {
                 const int nphi = phi + (1 << zb);
-                ctl_next = ctlp[nphi < N ? nphi : 0];
+                if constexpr (LAT) {
+                    if (((nphi ^ phi) & ~63) != 0) { ctlv = ctlv_n; ctlv_n = ctl_window((nphi & ~63) + 64); }     // (a block is at most 8 leaves: one window at a time)
+                    ctl_next = (uint32_t)__builtin_amdgcn_readlane((int)ctlv, nphi & 63);
+                } else ctl_next = ctlp[nphi < N ? nphi : 0];
             }
             const int lam_stop = n - zb;
             // recursivelyCalcLLR for this leaf, then the leaf itself (fragments of this function body: the kernel is one function, its

@@ -152,4 +152,35 @@ __device__ __forceinline__ void leaf_terms(double leaf, bool active, u64 actw, c
         spos = (al > 709.782712893384) ? __builtin_inf() : al + sneg;
     }
 }
+// The same terms for the one-codeword-per-wave kernels (exp-domain), K leaves at once (round 6): a lone wave pays an LDS round trip
+// for the table look-up of every logarithm, and the wave-uniform skips above put each of the 2 K logarithms into a basic block of
+// its own — 2 K round trips one after the other. Here all look-ups sit in ONE block (their reads issue together, one wait); the
+// values are those of leaf_terms<true> bit for bit: a lane the skips would have left alone computes log(1) = 0 (E <= 2^-53:
+// 1 + E == 1 -> q = 0 -> +0) or is overridden by its L-form select.
+template <int K>
+__device__ __forceinline__ void leaf_terms_ed_block(const double (&leaf)[K], u64 actw, const Tabs &tb, bool (&neg)[K], double (&al)[K], double (&sneg)[K], double (&spos)[K]) {
+    double m[K];
+    u64 any_e = 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        m[i] = fabs(leaf[i]);
+        neg[i] = (__double2hiint(leaf[i]) < 0) && m[i] != 1.0;
+        al[i] = m[i];
+        sneg[i] = 0.0;
+        any_e |= actw & __builtin_amdgcn_fcmp(m[i], 1.0, 13);           // ULE: active lanes holding an E-form value
+    }
+    if (POLAR_LIKELY2(any_e != 0)) {
+        double l[K], h[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            l[i] = -ed_log(__builtin_fmin(__builtin_fmax(m[i], ED_EMIN), 1.0), tb);
+            h[i] = log_1p2(__builtin_fmin(1.0 + m[i], 2.0), tb);
+        }
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+            if (!(m[i] > 1.0)) { al[i] = l[i]; sneg[i] = h[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < K; ++i) spos[i] = (al[i] > 709.782712893384) ? __builtin_inf() : al[i] + sneg[i];
+}
 }  // namespace

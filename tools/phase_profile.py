@@ -21,7 +21,7 @@ g = polar_amd.PolarCode(11, 1024, 0.32, 16)
 g.set_tuning(wpc, ll)
 llr = torch.empty((B, 2048), dtype=torch.float64, device="cuda")
 out = torch.empty((B, 1024), dtype=torch.uint8, device="cuda")
-prof = torch.zeros(max(B, 8), dtype=torch.int64, device="cuda")
+prof = torch.zeros(max(B, 64), dtype=torch.int64, device="cuda")
 g.synth_llr_dev(1, 0, B, g.snr_sqrt_linear(float(os.environ.get("EBNO", "2.0"))), llr.data_ptr())
 g.decode_scl_llr_dev(llr.data_ptr(), B, L, out.data_ptr(), prof.data_ptr())
 torch.cuda.synchronize()
