@@ -17,12 +17,15 @@ CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(ROOT, "include")
 LIB = os.path.join(HERE, "libpolar_amd.so")
 BUILD = os.path.join(HERE, "_build")
-# (source, extra -D, object tag, extra compiler options): polar_kernels.hip is compiled three times — LLR-domain kernel family,
-# exp-domain kernels of the small groups, exp-domain list of 32 (the headline kernel, with its own scheduler options)
+# (source, extra -D, object tag, extra compiler options): polar_kernels.hip is compiled four times — LLR-domain kernel family,
+# exp-domain kernels of the small groups, exp-domain list of 32 (the headline kernel, with its own scheduler options), exp-domain
+# one-codeword-per-wave kernels
 FLAGS_LIST32 = ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause", "-mllvm", "-amdgpu-use-amdgpu-trackers"] + \
                os.environ.get("POLAR_LIST32_FLAGS", "").split()          # (A/B experiments on the list-of-32 translation unit alone)
+# the one-codeword-per-wave kernels (a lone wave: every instruction is 4 cycles, a taken branch 20 — DESIGN.md §7)
+FLAGS_LAT = os.environ.get("POLAR_LAT_FLAGS", "").split()
 SOURCES = [("polar_kernels.hip", ["POLAR_ED_TU=0"], "", []), ("polar_kernels.hip", ["POLAR_ED_TU=1"], ".ed", []),
-           ("polar_kernels.hip", ["POLAR_ED_TU=2"], ".ed32", FLAGS_LIST32),
+           ("polar_kernels.hip", ["POLAR_ED_TU=2"], ".ed32", FLAGS_LIST32), ("polar_kernels.hip", ["POLAR_ED_TU=3"], ".lat", FLAGS_LAT),
            ("polar_kernels_sc.hip", [], "", []), ("polar_kernels_p1.hip", [], "", []), ("polar_channel.hip", [], "", []),
            ("polar_construct.hip", [], "", [])] + \
           [(f, [], "", []) for f in ("polar_handle.cpp", "polar_decode.cpp", "polar_hostpipe.cpp", "polar_montecarlo.cpp", "polar_multi.cpp",

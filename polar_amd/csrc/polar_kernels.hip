@@ -226,7 +226,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         // (same addresses for every path of the codeword: broadcast) until its first rewrite at phi = 2S.
         int phi_start = 0, forced_top = 0;
         const double *pre_cw = nullptr;
-        if (p.prefix_q > 0) {
+        if (!LAT && p.prefix_q > 0) {               // (the LAT form is launched without a prefix pass: its walk starts at leaf 0)
             const int Q = p.prefix_q, Pe = p.prefix_len;
             pre_cw = p.pre + (size_t)(valid ? cw : 0) * (size_t)(N - Q + 1);
             if (active) {
@@ -262,9 +262,11 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
         // (LAT, round 6) the two lowest layers are not stored: the four values of the layer of size 4 a path's current quad of leaves hangs
         // off (lat_x, read once per quad) and the two of the layer of size 2 (lat_y) ride in registers, replicated in the lanes of the
         // path like the rest of its state and copied with it by a clone (polar_scl_visits.inc, polar_scl_leaf.inc)
+        // lat_x is read at the first leaf of a quad and used again at its third, lat_y is set at the left leaf of a pair and used
+        // again at the right one: the walk of this form starts at leaf 0 and all-frozen blocks are aligned, so both are always there.
         double lat_x[4] = {0.0, 0.0, 0.0, 0.0}, lat_y0 = 0.0, lat_y1 = 0.0;
-        bool lat_xv = false, lat_yv = false;        // valid (wave-uniform)
-        (void)lat_x; (void)lat_y0; (void)lat_y1; (void)lat_xv; (void)lat_yv;
+        bool lat_yv = false;                        // (block lengths below 8 only: lat_y holds the pair's operands)
+        (void)lat_x; (void)lat_y0; (void)lat_y1; (void)lat_yv;
         auto ctl_window = [&](int w0) -> uint32_t { const int i_ = w0 + lane_id_opaque(); return p.ctl[i_ < N ? i_ : 0]; };
         uint32_t ctl_next;
         if constexpr (LAT) {
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(PIPE ? 64 : 256, PIPE ? 2 : OCC) void scl_decode_ll
             {
                 const int nphi = phi + (1 << zb);
                 if constexpr (LAT) {
-                    if (((nphi ^ phi) & ~63) != 0) { ctlv = ctlv_n; ctlv_n = ctl_window((nphi & ~63) + 64); }     // (a block is at most 8 leaves: one window at a time)
+                    if (POLAR_UNLIKELY2(((nphi ^ phi) & ~63) != 0)) { ctlv = ctlv_n; ctlv_n = ctl_window((nphi & ~63) + 64); }     // (a block is at most 8 leaves: one window at a time)
                     ctl_next = (uint32_t)__builtin_amdgcn_readlane((int)ctlv, nphi & 63);
                 } else ctl_next = ctlp[nphi < N ? nphi : 0];
             }
@@ -583,15 +585,15 @@ __global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p, int st
     }
 }
 
-// This file is compiled three times (polar_amd/build.py): POLAR_ED_TU = 0 instantiates the LLR-domain kernels and
+// This file is compiled four times (polar_amd/build.py): POLAR_ED_TU = 0 instantiates the LLR-domain kernels and
 // the small helper kernels, POLAR_ED_TU = 1 the exp-domain kernels of the groups of 4, 8, 16 and 64 lanes, POLAR_ED_TU = 2 the
-// exp-domain list of 32 — translation units that build in parallel, and the last one with its own scheduler options
+// exp-domain list of 32 — translation units that build in parallel, that one with its own scheduler options
 // (max-memory-clause strategy + the AMDGPU register-pressure trackers: +2.2 ... 3.8 % on the headline kernel, -11 % on the
-// groups of 8: build.py).
+// groups of 8: build.py) —, POLAR_ED_TU = 3 the exp-domain one-codeword-per-wave (LAT) kernels.
 #ifndef POLAR_ED_TU
 #define POLAR_ED_TU 0
 #endif
-#if POLAR_ED_TU != 2
+#if POLAR_ED_TU < 2
 #if POLAR_ED_TU
 hipError_t polar_launch_prefix_ed1(const PolarDecodeParams &p, double *ech_out, hipStream_t st) {
 #else
@@ -605,7 +607,7 @@ hipError_t polar_launch_prefix_ed0(const PolarDecodeParams &p, double *ech_out, 
     hipLaunchKernelGGL(prefix_kernel<POLAR_ED_TU != 0>, dim3((unsigned)blocks), dim3(256), staged ? stage : 0, st, p, staged, ech_out);
     return hipGetLastError();
 }
-#endif  // POLAR_ED_TU != 2
+#endif  // POLAR_ED_TU < 2
 
 #if !POLAR_ED_TU
 int polar_prefix_is_staged(int N) { return (N >= 64 && (size_t)8 * (size_t)(N / 2) * sizeof(double) <= 64 * 1024) ? 1 : 0; }
@@ -705,8 +707,9 @@ static hipError_t launch_gs(const PolarDecodeParams &p, int lds_log, int pipe, i
     return hipGetLastError();
 }
 
-// LAT instantiations (one codeword per wave, state in LDS): exp-domain arithmetic for the groups of 4 and 8 lanes (this
-// file compiled with POLAR_ED_TU = 1), LLR-domain for the groups of 2 (POLAR_ED_TU = 0)
+// LAT instantiations (one codeword per wave, state in LDS): exp-domain arithmetic for the groups of 2, 4 and 8 lanes in a translation
+// unit of their own (POLAR_ED_TU = 3, round 6: a lone wave wants code the throughput kernels do not — fewer branches, see
+// polar_amd/build.py FLAGS_LAT), LLR-domain arithmetic for the groups of 2 (POLAR_ED_TU = 0)
 template <int GS, bool ED>
 static hipError_t launch_lat(const PolarDecodeParams &p, int blocks, hipStream_t st) {
     const size_t lds = polar_decode_lat_lds_bytes(p.N, GS, p.W);
@@ -717,7 +720,7 @@ static hipError_t launch_lat(const PolarDecodeParams &p, int blocks, hipStream_t
     hipLaunchKernelGGL((scl_decode_llr_kernel<GS, 3, 1, ED, 0, 1>), dim3(blocks), dim3(64), lds, st, p);
     return hipGetLastError();
 }
-#if POLAR_ED_TU == 1
+#if POLAR_ED_TU == 3
 hipError_t polar_launch_decode_lat_ed1(const PolarDecodeParams &p, int gs, int blocks, hipStream_t st) {
     switch (gs) {
         case 2: return launch_lat<2, true>(p, blocks, st);
@@ -758,7 +761,7 @@ hipError_t polar_launch_decode_llr_ed1(const PolarDecodeParams &p, int gs, int l
         default: return hipErrorInvalidValue;
     }
 }
-#else
+#elif POLAR_ED_TU == 0
 hipError_t polar_launch_decode_llr_ed0(const PolarDecodeParams &p, int gs, int lds_log, int pipe, int grid, hipStream_t st) {
     switch (gs) {
         case 1: return launch_gs<1, false>(p, lds_log, pipe, grid, st);
