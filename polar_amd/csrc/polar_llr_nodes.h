@@ -170,11 +170,36 @@ __device__ __forceinline__ void leaf_terms_ed_block(const double (&leaf)[K], u64
         any_e |= actw & __builtin_amdgcn_fcmp(m[i], 1.0, 13);           // ULE: active lanes holding an E-form value
     }
     if (POLAR_LIKELY2(any_e != 0)) {
-        double l[K], h[K];
+        // ed_log / log_1p2 (polar_edom.h) split into "table slot" and "polynomial": the 4 K table values are read first — the empty asm
+        // needs all of them, so the reads are issued back to back and waited for once — then the polynomials run
+        double l[K], h[K], qa[K], qb[K], ea[K], rca[K], lca[K], rcb[K], lcb[K];
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-            l[i] = -ed_log(__builtin_fmin(__builtin_fmax(m[i], ED_EMIN), 1.0), tb);
-            h[i] = log_1p2(__builtin_fmin(1.0 + m[i], 2.0), tb);
+            const double x = __builtin_fmin(__builtin_fmax(m[i], ED_EMIN), 1.0);        // ed_log(x): exponent, mantissa in [1, 2)
+            const int hi = __double2hiint(x);
+            ea[i] = (double)((hi >> 20) - 1023);
+            const double ma = __hiloint2double((hi & 0x000FFFFF) | 0x3FF00000, __double2loint(x));
+            const double mb = __builtin_fmin(1.0 + m[i], 2.0);                          // log_1p2(1 + E)
+            double ca, cb;
+            const int ja = log_slot(ma, ca), jb = log_slot(mb, cb);
+            rca[i] = tb.RC[ja]; lca[i] = tb.LC[ja]; rcb[i] = tb.RC[jb]; lcb[i] = tb.LC[jb];
+            qa[i] = ma - ca; qb[i] = mb - cb;
+        }
+#pragma unroll
+        for (int i = 0; i < K; ++i) asm volatile("" : "+v"(rca[i]), "+v"(lca[i]), "+v"(rcb[i]), "+v"(lcb[i]));
+        auto poly = [](double q, double lc) {
+            double p = q * (-1.0 / 6.0) + 0.2;
+            p = __builtin_fma(p, q, -0.25);
+            p = __builtin_fma(p, q, 1.0 / 3.0);
+            p = __builtin_fma(p, q, -0.5);
+            p = __builtin_fma(p, q, 1.0);
+            return __builtin_fma(q, p, lc);
+        };
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const double la = poly(qa[i] * rca[i], lca[i]);
+            l[i] = -__builtin_fma(ea[i], 6.93147180369123816490e-01, __builtin_fma(ea[i], 1.90821492927058770002e-10, la));
+            h[i] = poly(qb[i] * rcb[i], lcb[i]);
         }
 #pragma unroll
         for (int i = 0; i < K; ++i)
