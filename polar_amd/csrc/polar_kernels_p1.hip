@@ -415,11 +415,21 @@ __global__ __launch_bounds__(64) void sc_p1_lat_kernel(PolarScP1Params p) {
     const int lane = threadIdx.x;
     const int n = p.n, N = p.N, K = p.K;
     double *ly = lds_p1, *lxl = ly + N, *lxr = lxl + N, *lu = lxr + N;
+    // A lone wave pays 4 cycles per instruction, ~ 50 per LDS round trip and a memory round trip (~ 1 us) for anything it reads from
+    // global memory inside the leaf loop (tools/lone_wave_microbench.hip): the frozen flags are staged in LDS once per block, the
+    // leaf's own node is evaluated by every lane from a broadcast read (not stored and read back), and the first level of the
+    // partial-sum update takes its two bits from registers.
+    unsigned char *lfz = reinterpret_cast<unsigned char *>(lu + N);
+    for (int i = lane; i < N; i += 64) lfz[i] = p.frozen[i];
+    wave_mem_fence();
     for (long cw = blockIdx.x; cw < p.B; cw += gridDim.x) {
         const double *y0 = p.p1 + (size_t)cw * N;
+        double xprev = 0.0;                                                          // decision of the pair's left leaf
         for (int phi = 0; phi < N; ++phi) {
+            const bool fz = lfz[phi] != 0;
             const int lam_top = phi ? (n - __builtin_ctz((unsigned)phi)) : 1;
-            for (int lam = lam_top; lam <= n; ++lam) {
+            const int lam_hi = (n > 1) ? n - 1 : n;
+            for (int lam = lam_top; lam <= lam_hi; ++lam) {
                 const int sh = n - lam, S = 1 << sh;
                 const bool odd = (phi >> sh) & 1;
                 for (int j = lane; j < S; j += 64) {
@@ -441,21 +451,37 @@ __global__ __launch_bounds__(64) void sc_p1_lat_kernel(PolarScP1Params p) {
                 }
                 wave_mem_fence();
             }
-            const double leaf = ly[1];
+            double leaf;
+            if (n > 1) {
+                // the leaf's node, by every lane: the two values of the layer of size 2 (a broadcast read), the left leaf's decision
+                const double a = ly[2], b = ly[3];
+                if ((phi & 1) == 0) leaf = a * (1 - b) + b * (1 - a);
+                else {
+                    const double w1 = xprev * (1 - a) + a * (1 - xprev);
+                    leaf = w1 * b / (w1 * b + (1 - w1) * (1 - b));
+                }
+            } else leaf = ly[1];
             double x;
-            if (p.frozen[phi]) x = 0.0;                                              // :875-876
+            if (fz) x = 0.0;                                                         // :875-876
             else { const double tt = 1 - 2 * leaf; x = (1 - (double)((tt > 0) - (tt < 0))) / 2; }   // :873
-            if (lane == 0) {
-                lu[phi] = x;
-                if ((phi & 1) == 0) lxl[1] = x; else lxr[1] = x;
-            }
-            wave_mem_fence();
-            if (phi & 1) {
-                int S = 1, ph = phi;
-                for (;;) {
-                    if (4 * S > N) break;
+            if (lane == 0) lu[phi] = x;
+            if ((phi & 1) == 0) {
+                xprev = x;
+                if (n == 1) { if (lane == 0) lxl[1] = x; wave_mem_fence(); }
+            } else if (4 <= N) {
+                // first level (S = 1) from registers: cnop(u1hard, u2hard) :885, then the generic walk from S = 2
+                int ph = phi >> 1;
+                bool to_right = ph & 1;
+                if (lane == 0) {
+                    double *dst = (to_right ? lxr : lxl) + 2;
+                    dst[0] = xprev * (1 - x) + x * (1 - xprev);
+                    dst[1] = x;
+                }
+                wave_mem_fence();
+                int S = 2;
+                while (to_right && 4 * S <= N) {
                     const int psi = ph >> 1;
-                    const bool to_right = psi & 1;
+                    to_right = psi & 1;
                     double *dst = (to_right ? lxr : lxl) + 2 * S;
                     for (int j = lane; j < S; j += 64) {
                         const double x1 = lxl[S + j], x2 = lxr[S + j];
@@ -463,16 +489,16 @@ __global__ __launch_bounds__(64) void sc_p1_lat_kernel(PolarScP1Params p) {
                         dst[j + S] = x2;
                     }
                     wave_mem_fence();
-                    if (!to_right) break;
                     S *= 2; ph = psi;
                 }
             }
         }
+        wave_mem_fence();
         for (int b = lane; b < K; b += 64) p.out[(size_t)cw * K + b] = lu[p.order[b]];
         wave_mem_fence();
     }
 }
-size_t polar_sc_p1_lat_lds_bytes(int N) { return (size_t)4 * N * sizeof(double); }
+size_t polar_sc_p1_lat_lds_bytes(int N) { return (size_t)4 * N * sizeof(double) + (size_t)N; }   // y, xl, xr, u + the frozen flags
 hipError_t polar_launch_sc_p1_lat(const PolarScP1Params &p, int grid, hipStream_t st) {
     const size_t lds = polar_sc_p1_lat_lds_bytes(p.N);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sc_p1_lat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
