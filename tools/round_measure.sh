@@ -2,7 +2,7 @@
 # tools/round_measure.sh — GPU box (via gpurun): the full measurement set of a round on the library in the tree, results under
 # gpurun_out/<tag>/ (copy what is to be judged into profiles/<round>/ with tools/pmc_summary.py, update_traffic*.py).
 # usage: tools/round_measure.sh <tag>
-T=${1:-r03}; O=gpurun_out/$T; mkdir -p $O
+T=${1:-r06}; O=gpurun_out/$T; mkdir -p $O
 sha256sum polar_amd/libpolar_amd.so > $O/lib_sha256.txt
 (timeout 1800 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3) > $O/gpu_tests.txt
 python bench.py > $O/bench.json 2> $O/bench.err
@@ -27,4 +27,7 @@ bash tools/config_pmc.sh $O/pmc config3 config5 > /dev/null 2>&1
 python tools/sc_rounds.py $O/sc_rounds.json > $O/sc_rounds.txt 2>&1
 python tools/config4_record.py 100 8388608 > $O/config4_record.json 2>> $O/bench.err
 python tools/fuzz_parity_p1.py 60 > $O/fuzz_p1.txt 2>&1
+bash tools/lat_pmc.sh $O/lat_pmc.txt 2 4 8 > /dev/null 2>&1
+python tools/sc_p1_time.py > $O/sc_p1_time.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 tools/lone_wave_microbench.hip -o /tmp/lw 2>/dev/null && /tmp/lw > $O/lone_wave_microbench.txt
 cat $O/gpu_tests.txt; tail -c 400 $O/bench_b524288.json; tail -2 $O/stress_parity.txt $O/fuzz_sane.txt $O/fuzz_any.txt
