@@ -189,17 +189,19 @@ int polar_host::decode_impl(polar_code *h, const void *d_llr, int llr_f32, long 
     const size_t lat_lds = polar_decode_lat_lds_bytes(h->N, gs, h->W);
     const long lat_resident = lat_lds <= h->lds_per_block ? (long)h->num_cu * std::min<long>(4, (long)(h->lds_per_block / lat_lds)) : 0;   // waves the LDS lets a device hold
     const bool lat_list = (gs == 2 || (ed && (gs == 4 || gs == 8))) && h->knobs.lat_max_b >= 0 && lat_resident > 0 &&
-                          B <= (h->knobs.lat_max_b ? h->knobs.lat_max_b : lat_resident);
-    // (measured, N = 2048: L = 4 B = 1 ... 256 2.45 ... 2.59 ms against 3.87 ... 4.36 ms for the batch kernel, L = 2 2.9 ... 3.0 against
-    // 5.9 ... 6.9 ms; beyond the waves the LDS lets the device hold at once — one per CU for lists of 4 and 8 at N = 2048, three for
-    // lists of 2 — the batch kernel wins: that is the default threshold)
+                          B <= (h->knobs.lat_max_b ? h->knobs.lat_max_b : 2 * lat_resident);
+    // (measured, N = 2048, round 6 — profiles/r06/latency_table_248.json: L = 4 B = 1 ... 256 1.80 ... 1.94 ms against 3.80 ... 4.36 ms
+    // for the batch kernel, L = 2 1.73 ... 2.09 against 5.9 ... 7.0 ms, L = 8 2.02 ... 2.17 against 3.83 ... 4.40. The LDS lets the
+    // device hold one wave per CU for lists of 4 and 8 at N = 2048, three for lists of 2; TWO rounds of that are still faster than
+    // the batch kernel — B = 512: 3.80 against 4.46 ms at L = 4, 4.25 against 4.59 at L = 8; B = 1024: 4.10 against 7.24 at L = 2 —,
+    // three are not: that is the default threshold)
     if (lat_list) {
         PolarDecodeParams pl = p;
         pl.prefix_q = 0; pl.prefix_len = 0; pl.pre = nullptr;
         const int blocks = (int)std::min<long>(B, lat_resident);
         if (lat_ed) {
             // (sized for the largest batch this path ever takes — a few hundred entries — so that the first call reserves it)
-            const size_t cap = (size_t)std::max<long>(B, lat_resident);
+            const size_t cap = (size_t)std::max<long>(B, 2 * lat_resident);
             if ((rc = h->d_flags.ensure(cap))) return rc;
             if ((rc = h->d_list.ensure(cap))) return rc;
             if ((rc = h->d_count.ensure(1))) return rc;
