@@ -438,7 +438,25 @@ __global__ __launch_bounds__(256) void prefix_kernel(PolarDecodeParams p, int st
                 if (ED && ech_out) {
                     double *erow = ech_out + (size_t)cw * (size_t)N;
                     bool any = false, sized = false;
-                    for (int m = lig; m < S; m += 32) {
+                    // (round 6: the loads of four pairs first — the stores to erow may alias the row as far as the compiler knows, so
+                    // the plain loop waited for memory once per pair: 32 round trips per lane on two waves per SIMD)
+                    int m = lig;
+                    for (; m + 96 < S; m += 128) {
+                        double x0[4], x1[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { x0[k] = CH(in0, 2 * (m + 32 * k)); x1[k] = CH(in0, 2 * (m + 32 * k) + 1); }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int mk = m + 32 * k;
+                            bool f0, f1;
+                            const double a = ed_from_channel(x0[k], tb, f0), b = ed_from_channel(x1[k], tb, f1);
+                            any |= f0 | f1;
+                            sized |= (fabs(x0[k]) >= 0.1) | (fabs(x1[k]) >= 0.1);
+                            erow[2 * mk] = a; erow[2 * mk + 1] = b;
+                            stg[__brev((unsigned)mk) >> (33 - n)] = FN(a, b);  // element j = bitrev_{n-1}(m)
+                        }
+                    }
+                    for (; m < S; m += 32) {
                         const double x0 = CH(in0, 2 * m), x1 = CH(in0, 2 * m + 1);
                         bool f0, f1;
                         const double a = ed_from_channel(x0, tb, f0), b = ed_from_channel(x1, tb, f1);

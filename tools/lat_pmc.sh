@@ -27,11 +27,11 @@ def grid(r):
     raise KeyError(str(list(r.keys())))
 for f in glob.glob(w + "/pmc*/**/pmc_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "decode" not in r["Kernel_Name"] or grid(r) != 64: continue
+        if ("decode" not in r["Kernel_Name"] and "lat_kernel" not in r["Kernel_Name"]) or grid(r) != 64: continue
         agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in glob.glob(w + "/pmc1/**/pmc_kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "decode" not in r["Kernel_Name"] or grid(r) != 64: continue
+        if ("decode" not in r["Kernel_Name"] and "lat_kernel" not in r["Kernel_Name"]) or grid(r) != 64: continue
         dur[r["Kernel_Name"].split("(")[0]].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 for k in sorted(agg):
     c = {n: sum(v) / len(v) for n, v in agg[k].items()}
