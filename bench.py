@@ -407,7 +407,9 @@ def monte_carlo_leg(args, code, dist, dev, rank, world, engine=None, native=True
         def sharded(max_runs, global_batch, stats=None):
             return get_bler_quick_sharded(engine, MC_GRID, Ls, max_runs=max_runs, max_err=no_stop, seed=args.seed, global_batch=global_batch, device=red_dev, stats=stats)
         drv = "polar_amd/montecarlo.py get_bler_quick_sharded, one rank per GPU, torch.distributed all-reduce per round"
-    sharded(min(total, per_round), per_round)           # warm-up (allocations)
+    # warm-up (allocations): THREE rounds — the merged batch of a step carries the survivors of the rounds before it, and its buffers
+    # reach their steady size only once the pipeline is full (one round alone left a 4-GiB reallocation inside the timed sweep: 3 %)
+    sharded(min(total, 3 * per_round), per_round)
     sync(); hbar()
     st = {}
     t0 = time.perf_counter()

@@ -70,8 +70,15 @@ int polar_host::decode_impl(polar_code *h, const void *d_llr, int llr_f32, long 
     // two tuned variants: "pipe" (8 waves/CU, S<=16 in LDS, register double-buffering) and the
     // default high-occupancy one (4-wave blocks, S<=8 in LDS, 16 waves/CU)
     int wpc = h->waves_per_cu ? h->waves_per_cu : 16;
+    int lds_log_auto = 0;
+    // Small batches of the large lists (no one-codeword-per-wave form: their state does not fit the LDS), round 6: when every group
+    // of the call is resident at ONE wave per SIMD anyway, fewer and fatter waves — layers up to 32 in LDS, the register-double-
+    // buffered form — answer sooner: a lone wave pays a memory round trip per dependent access of an HBM-resident layer
+    // (profiles/r06/small_batch_geometry.txt: L = 32 B = 256 5.10 -> 4.48 ms, L = 16 B = 1024 5.07 -> 4.64; nothing at 4096).
+    if (!h->waves_per_cu && !h->lds_log && gs >= 16 && (B + G - 1) / G <= (long)h->num_cu * 4 &&
+        polar_decode_lds_bytes(5, 1) <= h->lds_per_block) { wpc = 4; lds_log_auto = 5; }
     const int pipe = (wpc > 8) ? 0 : 1;
-    int lds_log = h->lds_log ? h->lds_log : (pipe ? 4 : 3);
+    int lds_log = h->lds_log ? h->lds_log : (lds_log_auto ? lds_log_auto : (pipe ? 4 : 3));
     const int wpb = polar_decode_waves_per_block(pipe);
     const size_t lds = polar_decode_lds_bytes(lds_log, pipe);
     const int max_blocks_by_lds = (int)(h->lds_per_block / lds);

@@ -141,31 +141,39 @@ def test_pipelined_host_batches_at_chunk_boundaries(built_lib, oracle_built, L):
 
 
 def test_pipelined_host_batch_at_the_default_settings(built_lib):
-    """The defaults (no knob): 16 384 codewords of the headline code at list sizes 1 and 4 (256 MiB of doubles)
-    through the host-pointer entry point == the device-resident decode of the same rows; a CRC matrix set in between
-    reaches every decode lane."""
+    """The defaults (no knob): 16 384 codewords of the headline code at list size 1 (256 MiB of doubles) and 32 768 at list
+    size 4 (512 MiB) through the host-pointer entry point == the device-resident decode of the same rows; 16 384 codewords at
+    list size 4 are BELOW the pipeline's threshold for the list kernels (round 6: one copy in, one launch, one copy out is
+    faster there); a CRC matrix set in between reaches every decode lane."""
     import ctypes as C
     import polar_amd
     import torch
     C.CDLL(None).srand(C.c_uint(1))
     g = polar_amd.PolarCode(11, 1024, 0.32, 16)
-    B = 16384
+    B = 32768
     d_llr = torch.empty((B, 2048), dtype=torch.float64, device="cuda")
     d_out = torch.empty((B, 1024), dtype=torch.uint8, device="cuda")
     g.synth_llr_dev(5, 0, B, g.snr_sqrt_linear(2.0), d_llr.data_ptr())
     llr = d_llr.cpu().numpy()
-    for L in (1, 4):
-        g.decode_scl_llr_dev(d_llr.data_ptr(), B, L, d_out.data_ptr())
+    for L, Bl in ((1, 16384), (4, 32768)):
+        g.decode_scl_llr_dev(d_llr.data_ptr(), Bl, L, d_out.data_ptr())
         torch.cuda.synchronize()
-        got = g.decode_scl_llr(llr, L)
-        # (256 MiB: full-size chunks of 64 MiB, i.e. 4096 codewords; 512 + 1024 + 2048 first, then 4 x 3200)
+        got = g.decode_scl_llr(llr[:Bl], L)
+        # (L = 1, 256 MiB: full-size chunks of 64 MiB, i.e. 4096 codewords; 512 + 1024 + 2048 first, then 4 x 3200.
+        #  L = 4, 512 MiB: chunks of 128 MiB, i.e. 8192 codewords; 1024 + 2048 + 4096 first, then 4 x 6400)
         assert g.debug_get("host_chunks") == 7 and g.debug_get("host_lanes") == (2 if L == 1 else 3)
-        assert (got == d_out.cpu().numpy()).all()
-    m = g.crc_matrix
-    g.crc_matrix = m[::-1].copy()
+        assert (got == d_out[:Bl].cpu().numpy()).all()
+    B = 16384
     g.decode_scl_llr_dev(d_llr.data_ptr(), B, 4, d_out.data_ptr())
     torch.cuda.synchronize()
-    assert (g.decode_scl_llr(llr, 4) == d_out.cpu().numpy()).all()
+    got = g.decode_scl_llr(llr[:B], 4)
+    assert g.debug_get("host_chunks") == 0 and (got == d_out[:B].cpu().numpy()).all()
+    m = g.crc_matrix
+    g.crc_matrix = m[::-1].copy()
+    B = 32768                                                              # (pipelined again: the lanes' private tables)
+    g.decode_scl_llr_dev(d_llr.data_ptr(), B, 4, d_out.data_ptr())
+    torch.cuda.synchronize()
+    assert (g.decode_scl_llr(llr, 4) == d_out.cpu().numpy()).all() and g.debug_get("host_chunks") == 7
 
 
 @pytest.mark.parametrize("lds_log", [3, 4, 5])
