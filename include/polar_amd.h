@@ -91,7 +91,7 @@ int polar_decode_scl_llr(polar_code_t *h, const double *llr /*[N]*/, int L, uint
  * up to 2048 codewords (N <= 4096), list sizes 2 .. 8 up to one codeword per CU while the state fits 160 KiB of LDS (N = 2048: lists
  * up to 4; N = 1024: up to 8). Same bits as the batch kernels (tests/: every such test runs both). Batches of at most 64
  * codewords at list size 1 are staged in pinned, device-mapped host memory (no DMA copies).
- * Large batches (from 32 MiB of LLRs at L = 1, 1 GiB at L = 2, 384 MiB at L = 3 .. 8, 192 MiB for larger lists: below that one copy in, one launch and one copy out is faster) are PIPELINED inside the call: chunks are copied from the caller's (pageable) memory into
+ * Large batches (from 32 MiB of LLRs at L = 1, 1 GiB at L = 2, half a GiB or one full round of resident waves at L = 3 .. 8, half a GiB or two rounds for larger lists: below that one copy in, one launch and one copy out is faster) are PIPELINED inside the call: chunks are copied from the caller's (pageable) memory into
  * pinned slots by a few host threads, moved on a copy stream and decoded on two or three decode lanes with their own scratch
  * (the handle keeps slots, streams, lanes and threads: 0.3 - 1.3 GiB of pinned and device memory after the first such call):
  * min(device rate, PCIe rate) minus one decode launch, whatever the batch size; device memory use is bounded by the slots,

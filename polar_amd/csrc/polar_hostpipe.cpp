@@ -194,13 +194,16 @@ static int host_decode(polar_code_t *h, const void *llr, int llr_f32, long B, in
     {
         const polar_code::Knobs &kn = h->knobs;
         // From where the pipeline pays (round 6, tools/host_pipe_crossover.py, profiles/r06/host_pipe_crossover.json): n chunks on k lanes
-        // are n / k launch latencies of 4 .. 8 ms for the list kernels, so below a copy time of about one launch ONE copy in, ONE
-        // launch and one copy out is faster — 2048 .. 16384 codewords of N = 2048 at L = 4: 5.0 .. 10.5 ms against 16.0 .. 14.9 ms
-        // pipelined (the 32-MiB rule of round 5), L = 32 up to 8192: 5.8 .. 13.2 against 15.3 .. 17.7 ms. Measured crossovers:
-        // L = 1 32 MiB, L = 2 (the LLR-domain 2-lane kernel: the slowest launches) 1 GiB, L = 3 .. 8 between 256 and 512 MiB,
-        // larger lists between 128 and 256 MiB of LLRs.
-        const size_t pipe_from = L == 1 ? (size_t)32 << 20 : L == 2 ? (size_t)1 << 30 : L <= 8 ? (size_t)384 << 20 : (size_t)192 << 20;
-        const size_t min_bytes = kn.host_pipe_min_bytes > 0 ? (size_t)kn.host_pipe_min_bytes : pipe_from;
+        // are n / k launch latencies of 4 .. 8 ms for the list kernels, so while the whole batch fits the device's resident waves and
+        // its copy takes less than about one launch, ONE copy in, ONE launch and one copy out is faster — 2048 .. 16384 codewords of
+        // N = 2048 at L = 4: 5.0 .. 10.5 ms against 16.0 .. 14.9 ms pipelined (the 32-MiB rule of round 5), L = 32 up to 8192: 5.8 ..
+        // 13.2 against 15.3 .. 17.7 ms. Measured crossovers: L = 1 32 MiB; L = 2 (the LLR-domain 2-lane kernel: the slowest launches)
+        // 1 GiB; L = 3 .. 8 half a GiB of LLRs or one full round of resident waves, whichever comes first (N = 1024, L = 8, 65536
+        // float rows = 256 MiB = two rounds: 12.0 ms pipelined, 17.7 in one copy); larger lists half a GiB or two rounds.
+        const long resident_cw = (long)h->num_cu * 16 * (64 / pow2ceil(L));
+        const bool pays = L == 1 ? in_bytes >= ((size_t)32 << 20) : L == 2 ? in_bytes >= ((size_t)1 << 30)
+                                 : (in_bytes >= ((size_t)512 << 20) || B >= (L <= 8 ? 1 : 2) * resident_cw);
+        const size_t min_bytes = kn.host_pipe_min_bytes > 0 ? (size_t)kn.host_pipe_min_bytes : (pays ? 0 : ~(size_t)0);
         if (kn.host_pipe_min_bytes >= 0 && in_bytes >= min_bytes) {
             // full-size chunks: 64 MiB of LLRs at list size 1 (the link is the bound, its kernel answers in a millisecond). The
             // list kernels' launches take 4 .. 8 ms whatever they carry, and the chunks in flight must cover what the link
