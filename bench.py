@@ -1020,7 +1020,20 @@ def latency_record(args, code):
         okp = okp and bool((got == want_p[i % 8]).all())
     rows.append({"call": "decode_sc_p1", "gpu_call_ms": float(np.median(ts)) * 1e3, "cpu_ms_per_codeword_one_core": cpu_p_ms, "cpu_kind": "port (C restatement of PolarM's recursion)",
                  "bits_equal": okp})
-    return {"abi": "polar_decode_scl_llr (host pointers, one codeword per call)", "rows": rows}
+    # mid-size host batches (64 MiB of doubles): between one codeword per call and the pipelined batches of `host_batch` — one
+    # copy in, ONE launch, one copy out since round 6 (the 32-MiB pipeline rule cost these calls a factor of 2-3)
+    mid = []
+    for L in (4, 32):
+        want = cpu.decode_scl_llr(llr, L)
+        x = np.ascontiguousarray(np.tile(llr, (512, 1)))
+        got = code.decode_scl_llr(x, L)
+        ok = bool((got == np.tile(want, (512, 1))).all())
+        ts = []
+        for _ in range(5):
+            t = time.perf_counter(); code.decode_scl_llr(x, L); ts.append(time.perf_counter() - t)
+        mid.append({"L": L, "batch": len(x), "llr_MiB": x.nbytes / 2 ** 20, "gpu_call_ms": float(np.median(ts)) * 1e3, "value": len(x) / float(np.median(ts)),
+                    "unit": "codewords/s", "bits_equal": ok, "chunks": code.debug_get("host_chunks")})
+    return {"abi": "polar_decode_scl_llr (host pointers, one codeword per call)", "rows": rows, "mid_size_batches": mid}
 
 
 def other_configs(args, dev):
