@@ -11,7 +11,7 @@ python tools/update_traffic.py $P/final_headline_pmc.json 11 1024 16 32 262144 >
 python tools/update_traffic_configs.py $P config1 config2 config2_b262144 config3 config5 config3_b262144 config5_b262144 > /dev/null
 for f in bench.json bench_b524288.json bler_sweeps.json config4_record.json lib_sha256.txt gpu_tests.txt stress_parity.txt fuzz_sane.txt fuzz_any.txt fuzz_p1.txt \
          fresh_out_probe.json traffic_replay_raw.txt sc_rounds.json icache_pmc.txt stall_pmc.txt cache_footprint_microbench.txt latency_table.json host_path_65536.json host_path_262144.json \
-         host_trace_config3.txt lat_pmc.txt sc_p1_time.txt lone_wave_microbench.txt; do cp $O/$f $P/ 2>/dev/null || echo "missing $f"; done
+         host_trace_config3.txt lat_pmc.txt sc_p1_time.txt lone_wave_microbench.txt stress_parity_lat.txt; do cp $O/$f $P/ 2>/dev/null || echo "missing $f"; done
 cp gpurun_out/fuzz_slice.json $P/ 2>/dev/null || true
 for c in config3 config5; do cp $O/pmc/$c.txt $P/final_pmc_$c.txt 2>/dev/null || true; done
 python - <<EOF

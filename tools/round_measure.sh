@@ -29,5 +29,6 @@ python tools/config4_record.py 100 8388608 > $O/config4_record.json 2>> $O/bench
 python tools/fuzz_parity_p1.py 60 > $O/fuzz_p1.txt 2>&1
 bash tools/lat_pmc.sh $O/lat_pmc.txt 2 4 8 > /dev/null 2>&1
 python tools/sc_p1_time.py > $O/sc_p1_time.txt 2>&1
+python tools/stress_parity_lat.py 8192 > $O/stress_parity_lat.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 tools/lone_wave_microbench.hip -o /tmp/lw 2>/dev/null && /tmp/lw > $O/lone_wave_microbench.txt
 cat $O/gpu_tests.txt; tail -c 400 $O/bench_b524288.json; tail -n 2 $O/stress_parity.txt $O/fuzz_sane.txt $O/fuzz_any.txt
